@@ -1,0 +1,203 @@
+/*
+ * pt_api.h — C ABI of the MI355X path-tracing core (libpt_hip.so).
+ *
+ * This is the drop-in boundary for the reference's offline render path.  The
+ * reference (jayHuggie/PathTracer_CUDA_Interactive) has no plugin/FFI API; the
+ * seam is "upload the flattened Scene, seed the RNG, launch `render`, sync":
+ *
+ *   reference call site                       replaced by
+ *   ----------------------------------------  ---------------------------------
+ *   GPUScene::copyFrom        scene.h:73-119   pt_scene_create
+ *   copyTriangleMeshToDevice  shape.cuh:48-59  pt_scene_create (mesh arrays)
+ *   copyBVHNodesToDevice2     bvh.cu:83-97     pt_scene_create (node array)
+ *   setup_rand<<<>>>          main.cu:54-62,234  (folded into pt_render: O(1) PCG init)
+ *   render<<<>>> + sync       main.cu:30-52,258-260   pt_render / pt_render_async
+ *   render_progressive<<<>>>  main.cu:64-89,333       pt_render_accumulate
+ *   GPUScene::free            scene.h:144-171  pt_scene_destroy
+ *   checkCudaErrors -> exit   bbox.cuh:7-17    int status + pt_last_error()
+ *
+ * All structs are plain C PODs mirroring the reference's host `Scene`
+ * (scene.h:17-35): shapes, meshes, materials, lights, BVH nodes.  The caller
+ * owns every input array; pt_scene_create copies what it needs (and re-lays it
+ * out for the GPU), so inputs may be freed right after it returns.
+ *
+ * No torch / C++ types cross this boundary.  Thread-compatible: no hidden
+ * global state except the thread-local error string.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API_VERSION 1
+
+/* status codes (0 = ok).  The reference exits the process instead (bbox.cuh:9-17). */
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = 1,
+    PT_ERR_BAD_SCENE = 2,      /* inconsistent ids / topology / BVH deeper than the stack cap */
+    PT_ERR_DEVICE = 3,         /* HIP runtime error */
+    PT_ERR_NO_DEVICE = 4,
+    PT_ERR_IO = 5,
+    PT_ERR_PARSE = 6,
+    PT_ERR_UNSUPPORTED = 7
+};
+
+/* shape.cuh:61  enum ShapeType {SPHERE, TRIANGLE} */
+enum { PT_SHAPE_SPHERE = 0, PT_SHAPE_TRIANGLE = 1 };
+/* material.h:27 enum MaterialType { DIFFUSE, MIRROR, PLASTIC, PHONG } */
+enum { PT_MAT_DIFFUSE = 0, PT_MAT_MIRROR = 1, PT_MAT_PLASTIC = 2, PT_MAT_PHONG = 3 };
+/* light.h:17    enum LightType { POINTLIGHT, DIFFUSEAREALIGHT } */
+enum { PT_LIGHT_POINT = 0, PT_LIGHT_DIFFUSE_AREA = 1 };
+
+/* Shape (shape.cuh:63-69): tagged union of Sphere{mat,light,center,radius}
+ * and Triangle{face_index, mesh_index}.  Flattened here (no union) so that
+ * ctypes / cgo / JNI can bind it without tricks. */
+typedef struct pt_shape {
+    int32_t type;            /* PT_SHAPE_* */
+    int32_t material_id;     /* sphere only (triangles take the mesh's)   */
+    int32_t area_light_id;   /* sphere only; -1 = not emissive            */
+    float   center[3];       /* sphere */
+    float   radius;          /* sphere */
+    int32_t face_index;      /* triangle: index into mesh indices         */
+    int32_t mesh_index;      /* triangle: index into pt_scene_desc.meshes */
+} pt_shape;
+
+/* TriangleMesh (shape.cuh:28-41) minus the device pointers and the UVs
+ * (UVs never influence the result: texture.h:69-71 is constant-colour only). */
+typedef struct pt_mesh {
+    int32_t material_id;
+    int32_t area_light_id;       /* -1 = not emissive */
+    int32_t num_vertices;
+    int32_t num_faces;
+    const float*   positions;    /* [num_vertices*3] */
+    const int32_t* indices;      /* [num_faces*3]    */
+    const float*   normals;      /* [num_vertices*3], REQUIRED (every shipped scene has them) */
+} pt_mesh;
+
+/* Material (material.h:8-36).  Textures are constant colours (texture.h:12-15). */
+typedef struct pt_material {
+    int32_t type;            /* PT_MAT_* */
+    float   reflectance[3];
+    float   eta;             /* PLASTIC index of refraction */
+    float   exponent;        /* PHONG exponent              */
+} pt_material;
+
+/* Light (light.h:5-27).  Only DiffuseAreaLight::radiance is ever read by the
+ * hot path (radiance.cuh:36-41); point lights are carried for fidelity. */
+typedef struct pt_light {
+    int32_t type;            /* PT_LIGHT_* */
+    int32_t shape_id;        /* area light: emitting shape */
+    float   radiance[3];     /* area: radiance; point: intensity */
+    float   position[3];     /* point light only */
+} pt_light;
+
+/* BVHNode (bvh.cuh:7-15) minus the two unused device pointers. */
+typedef struct pt_bvh_node {
+    float   bmin[3];
+    float   bmax[3];
+    int32_t left;            /* -1 on leaves */
+    int32_t right;           /* -1 on leaves */
+    int32_t prim;            /* shape index on leaves, -1 on inner nodes */
+} pt_bvh_node;
+
+/* The flattened scene: what Scene (scene.h:17-35) holds after its ctor ran. */
+typedef struct pt_scene_desc {
+    int32_t num_shapes;     const pt_shape*    shapes;
+    int32_t num_meshes;     const pt_mesh*     meshes;
+    int32_t num_materials;  const pt_material* materials;
+    int32_t num_lights;     const pt_light*    lights;
+    int32_t num_nodes;      const pt_bvh_node* nodes;     /* 2*num_shapes-1, post-order (bvh.cu:16-54) */
+    int32_t root;           /* = num_nodes-1 for the reference builder */
+    float   background[3];
+} pt_scene_desc;
+
+/* Per-render inputs: what `render` takes by value (main.cu:30-31) plus the
+ * constants the reference hard-codes (seed 1984 main.cu:61; MAX_DEPTH 50
+ * radiance.cuh:12; RR after depth>5 radiance.cuh:68). */
+typedef struct pt_render_params {
+    float    cam_origin[3];          /* CameraRayData (camera.cuh:21-26) */
+    float    cam_top_left[3];
+    float    cam_horizontal[3];
+    float    cam_vertical[3];
+    int32_t  width, height;          /* full image size (u,v and pixel_index use these) */
+    int32_t  spp;                    /* samples rendered by this call */
+    int32_t  row_begin, row_end;     /* rows [row_begin,row_end) rendered by this call; 0,0 = all.  Multi-GPU shard. */
+    int32_t  row_stride;             /* 0/1 = contiguous rows; k>1 = rows row_begin, row_begin+k, ... < row_end (interleaved bands of 1 row) */
+    uint64_t seed;                   /* PCG seed (reference literal: 1984) */
+    int32_t  max_depth;              /* 0 -> 50 */
+    int32_t  rr_depth;               /* Russian roulette when depth > rr_depth; <0 -> 5 */
+    int32_t  sample_offset;          /* first absolute sample index of this call (progressive) */
+    int32_t  stream_stride;          /* PCG stream = pixel_index*stream_stride + sample_offset + s; 0 -> spp */
+    int32_t  traversal;              /* PT_TRAVERSAL_* */
+    int32_t  reserved;
+} pt_render_params;
+
+enum {
+    PT_TRAVERSAL_DEFAULT = 0,        /* library picks (currently EXACT) */
+    PT_TRAVERSAL_EXACT   = 1,        /* visit exactly the nodes the reference visits (no closest-t pruning, scene.h:278-297) */
+    PT_TRAVERSAL_PRUNED  = 2         /* skip subtrees whose box entry is beyond the closest hit; same image, fewer visits */
+};
+
+/* Work counters of the last pt_render* call on a scene (device-side 64-bit
+ * sums).  `segments` = number of intersect() calls = the "samples" of the
+ * Msamples/s metric. */
+typedef struct pt_counters {
+    uint64_t paths;
+    uint64_t segments;
+    uint64_t node_visits;      /* inner-node pops actually executed by the kernel */
+    uint64_t leaf_tests;       /* primitive tests actually executed */
+    double   kernel_ms;        /* hipEvent time of the trace kernel(s) of the last call */
+    double   resolve_ms;       /* hipEvent time of the per-pixel resolve kernel(s) */
+} pt_counters;
+
+typedef struct pt_scene pt_scene;    /* opaque: owns all device memory of one scene on one GPU */
+
+/* Create a device scene on the CURRENT HIP device.  Validates ids/topology
+ * (PT_ERR_BAD_SCENE instead of device printf: scene.h:260-263). */
+int pt_scene_create(const pt_scene_desc* desc, pt_scene** out);
+int pt_scene_destroy(pt_scene* scene);
+
+/* Blocking render.  `fb` receives rows x width x 3 floats, rows = the rows
+ * selected by (row_begin,row_end,row_stride), packed in increasing row order;
+ * fb[(r*W+i)*3+c], linear radiance, row 0 = top (main.cu:35,50).
+ * fb_on_device != 0: fb is a device pointer on the scene's GPU. */
+int pt_render(pt_scene* scene, const pt_render_params* p, float* fb, int fb_on_device);
+
+/* Same, enqueued on a caller-provided hipStream_t (NULL = default stream); fb
+ * must be a device pointer; returns without synchronising. */
+int pt_render_async(pt_scene* scene, const pt_render_params* p, float* fb_dev, void* hip_stream);
+
+/* Progressive accumulation (render_progressive, main.cu:64-89): adds the SUM
+ * of p->spp new samples (absolute indices sample_offset..) into accum_dev
+ * (same layout as fb; overwritten when sample_offset == 0).  Async on stream. */
+int pt_render_accumulate(pt_scene* scene, const pt_render_params* p, float* accum_dev, void* hip_stream);
+
+int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the scene's last stream */
+
+/* Tuning knobs (all optional): blocks per CU of the persistent kernel (0=auto),
+ * scratch cap in bytes for per-sample radiance (0=auto), kernel variant. */
+int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
+int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
+
+/* Deterministic fp32 helpers evaluated ON THE DEVICE, exported so tests can
+ * pin device arithmetic against the CPU oracle bit-for-bit.
+ * op: 0 sincos(x)->(sin,cos)  1 powf(x,y)  2 pcg32 floats (x = stream as float bits ignored; see impl) */
+int pt_debug_math(int op, const float* x, const float* y, float* out0, float* out1, int n);
+
+/* Closest-hit query for explicit rays (tests / per-ray KATs).
+ * rays: n x {org[3], dir[3], tnear, tfar}; out: n x {t,u,v} and prim id (-1 = miss). */
+int pt_debug_intersect(pt_scene* scene, const float* rays, int n, int traversal,
+                       float* out_tuv, int32_t* out_prim);
+
+const char* pt_last_error(void);
+int pt_api_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

@@ -1,0 +1,77 @@
+"""In-tree builds of the native libraries (no JIT cache: the .so files travel with the repo).
+
+  libpt_host.so  — g++   : host scene pipeline (csrc/host/*.cpp)
+  libpt_hip.so   — hipcc : C ABI + HIP kernels for gfx950 (csrc/*.hip)
+
+`-ffp-contract=off` on BOTH is part of the numerical contract:
+the device kernels must round exactly like the CPU oracle.
+"""
+import os
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(REPO_DIR, "include")
+
+HOST_LIB = os.path.join(PKG_DIR, "libpt_host.so")
+HIP_LIB = os.path.join(PKG_DIR, "libpt_hip.so")
+
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off"]
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
+    "-ffp-contract=off",                      # no FMA contraction: bit-parity with the oracle
+    "-fno-gpu-flush-denormals-to-zero",       # keep fp32 denormals (x86 does)
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _glob(d, exts):
+    out = []
+    for root, _, files in os.walk(d):
+        for f in sorted(files):
+            if f.endswith(exts):
+                out.append(os.path.join(root, f))
+    return out
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_host(force=False):
+    srcs = _glob(os.path.join(CSRC, "host"), (".cpp",))
+    deps = srcs + _glob(os.path.join(CSRC, "host"), (".h",)) + _glob(INCLUDE, (".h",))
+    if force or _newer(HOST_LIB, deps):
+        _run(["g++"] + HOST_FLAGS + ["-I", INCLUDE, "-o", HOST_LIB] + srcs)
+    return HOST_LIB
+
+
+def build_hip(force=False, extra_flags=()):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + _glob(INCLUDE, (".h",))
+    if force or _newer(HIP_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIP_FLAGS + list(extra_flags) + ["-I", INCLUDE, "-I", CSRC, "-o", HIP_LIB] + srcs)
+    return HIP_LIB
+
+
+def build_all(force=False):
+    return build_host(force), build_hip(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

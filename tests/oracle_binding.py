@@ -1,0 +1,124 @@
+"""ctypes binding of the CPU oracle (oracle/libpt_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pathtracer_cuda_interactive_amd.ctypes_defs import PT_OK, PtError, PtRenderParams, PtSceneDesc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(REPO, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libpt_oracle.so")
+
+MATH_DET, MATH_LIBM = 0, 1
+RNG_PER_SAMPLE, RNG_PER_PIXEL = 0, 1
+
+
+class OracleOpts(C.Structure):
+    _fields_ = [("math_mode", C.c_int32), ("rng_mode", C.c_int32), ("threads", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("paths", "segments", "inner_pops", "leaf_tri", "leaf_sphere", "valid_hits", "closer_hits", "closer_tri",
+                 "rng_draws", "emit", "term_miss", "term_rr", "term_absorb", "term_maxdepth", "max_stack",
+                 "stack_overflow")] + [("seconds", C.c_double), ("threads_used", C.c_int32), ("pad", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+
+    def bytes_per_segment(self):
+        """Algorithmic bytes per segment of the REFERENCE layout:
+        inner pop 60 B, triangle leaf 120 B, sphere leaf 32 B, +60 B per closer TRIANGLE hit (3 normals + 3 uvs), 40 B shade."""
+        s = float(self.segments)
+        return (60.0 * self.inner_pops + 120.0 * self.leaf_tri + 32.0 * self.leaf_sphere + 60.0 * self.closer_tri) / s + 40.0
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    return ORACLE_LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            build()
+        L = C.CDLL(ORACLE_LIB)
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.pt_oracle_render.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRenderParams), C.POINTER(OracleOpts), fp,
+                                       C.POINTER(OracleCounters)]
+        L.pt_oracle_render_pixels.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRenderParams), C.POINTER(OracleOpts),
+                                              ip, C.c_int, fp, C.POINTER(OracleCounters)]
+        L.pt_oracle_intersect.argtypes = [C.POINTER(PtSceneDesc), fp, C.c_int, C.c_int, fp, ip]
+        L.pt_oracle_math.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.c_int]
+        L.pt_oracle_pcg.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def _chk(rc, what):
+    if rc != PT_OK:
+        raise PtError(rc, what)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def render(desc, params, math_mode=MATH_DET, rng_mode=RNG_PER_SAMPLE, threads=0, accumulate=False):
+    """Returns (image[rows,W,3] float32, OracleCounters)."""
+    opts = OracleOpts(math_mode, rng_mode, threads, 1 if accumulate else 0)
+    img = np.zeros((params.num_rows(), params.width, 3), dtype=np.float32)
+    cnt = OracleCounters()
+    _chk(lib().pt_oracle_render(C.byref(desc), C.byref(params), C.byref(opts), _fp(img), C.byref(cnt)), "oracle render")
+    return img, cnt
+
+
+def render_pixels(desc, params, xy, math_mode=MATH_DET, rng_mode=RNG_PER_SAMPLE, threads=0):
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((xy.shape[0], 3), dtype=np.float32)
+    opts = OracleOpts(math_mode, rng_mode, threads, 0)
+    cnt = OracleCounters()
+    _chk(lib().pt_oracle_render_pixels(C.byref(desc), C.byref(params), C.byref(opts),
+                                       xy.ctypes.data_as(C.POINTER(C.c_int32)), xy.shape[0], _fp(out), C.byref(cnt)),
+         "oracle render_pixels")
+    return out, cnt
+
+
+def intersect(desc, rays, math_mode=MATH_DET):
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+    tuv = np.zeros((rays.shape[0], 3), dtype=np.float32)
+    prim = np.zeros(rays.shape[0], dtype=np.int32)
+    _chk(lib().pt_oracle_intersect(C.byref(desc), _fp(rays), rays.shape[0], math_mode, _fp(tuv),
+                                   prim.ctypes.data_as(C.POINTER(C.c_int32))), "oracle intersect")
+    return tuv, prim
+
+
+def sincos(x, math_mode=MATH_DET):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    _chk(lib().pt_oracle_math(0, math_mode, _fp(x), _fp(x), _fp(s), _fp(c), x.size), "oracle math")
+    return s, c
+
+
+def powf(x, y, math_mode=MATH_DET):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    o = np.zeros_like(x)
+    _chk(lib().pt_oracle_math(1, math_mode, _fp(x), _fp(y), _fp(o), _fp(o), x.size), "oracle math")
+    return o
+
+
+def pcg(stream, seed, n):
+    u = np.zeros(n, dtype=np.uint32)
+    f = np.zeros(n, dtype=np.float32)
+    si = (C.c_uint64 * 2)()
+    _chk(lib().pt_oracle_pcg(int(stream), int(seed), n, u.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(f), si), "pcg")
+    return u, f, (int(si[0]), int(si[1]))
