@@ -1,0 +1,798 @@
+// pt_api.hip — kernels and C ABI of libpt_hip.so (gfx950 only).  See include/pt_api.h.
+//
+// Kernels
+//   trace_kernel<LDS_SCENE,PRUNE,STATS>  persistent wavefront path tracer: one path per lane,
+//        dead lanes are refilled from a global work counter (wave-granular chunks, __ballot +
+//        mbcnt ranks), traversal stack per wave in LDS, small scenes staged entirely in LDS.
+//        Replaces render + setup_rand (main.cu:30-62) and everything they call.
+//   resolve_kernel   ordered per-pixel sum of the per-sample radiances (main.cu:47,50) — keeps
+//        the reference's summation order although lanes finish paths out of order.
+//   intersect_kernel / math_kernel        test hooks (pt_debug_*).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "pt_layout.h"
+#include "pt_math.h"
+#include "pt_trace.h"
+
+using namespace ptl;
+
+// ------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr uint32_t kChunk = 256;     // work items a wave reserves per atomic
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void stage_to_lds(void* dst, const void* src, uint32_t bytes) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    const float4* s = reinterpret_cast<const float4*>(src);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+
+template <bool LDS_SCENE, bool PRUNE, bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev rp, LdsPlan lp,
+                                                       float4* __restrict__ samples,
+                                                       uint32_t* __restrict__ work_counter,
+                                                       unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ptd::SceneView sv;
+    if (LDS_SCENE) {
+        stage_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes * sizeof(DNode));
+        stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
+        stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
+        stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
+        stage_to_lds(smem + lp.emis_off, scn.emission, (uint32_t)scn.num_emission * sizeof(DEmission));
+        __syncthreads();
+        sv.nodes = reinterpret_cast<const DNode*>(smem + lp.nodes_off);
+        sv.prims = reinterpret_cast<const DPrim*>(smem + lp.prims_off);
+        sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
+        sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
+        sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
+    } else {
+        sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
+        sv.materials = scn.materials; sv.emission = scn.emission;
+    }
+    sv.num_emission = scn.num_emission;
+    sv.root_ref = scn.root_ref;
+    sv.bg = ptm::mk(scn.bg[0], scn.bg[1], scn.bg[2]);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
+
+    uint32_t chunk_cur = 0, chunk_end = 0;
+    bool exhausted = false;
+    bool alive = false;
+    ptd::Ray ray;
+    ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
+    ptm::Pcg rng;
+    rng.state = 0; rng.inc = 1;
+    int depth = 0;
+    uint32_t my_w = 0;
+    uint32_t n_paths = 0, n_segs = 0;
+    ptd::TravStats st;
+    st.nodes = 0; st.leaves = 0;
+    ray.org = ptm::mk(0, 0, 0); ray.dir = ptm::mk(0, 0, 1); ray.tnear = 0; ray.tfar = 0;
+
+    for (;;) {
+        // ---- refill dead lanes with new paths
+        const unsigned long long need = __ballot(!alive);
+        if (need) {
+            if (chunk_cur >= chunk_end && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, kChunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= rp.total_work) exhausted = true;
+                else { chunk_cur = base; chunk_end = min(base + kChunk, rp.total_work); }
+            }
+            const uint32_t avail = chunk_end - chunk_cur;
+            if (avail) {
+                const uint32_t rank = lane_rank(need);
+                const uint32_t n = (uint32_t)__popcll(need);
+                if (!alive && rank < avail) {
+                    // main.cu:32-44 for work item w = (sample, pixel)
+                    const uint32_t w = chunk_cur + rank;
+                    const uint32_t s_local = w / rp.npix;
+                    const uint32_t pix = w - s_local * rp.npix;
+                    const uint32_t r = pix / (uint32_t)rp.width;
+                    const int i = (int)(pix - r * (uint32_t)rp.width);
+                    const int j = rp.row_begin + (int)r * rp.row_step;
+                    const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;
+                    const uint64_t stream = pixel_index * (uint64_t)rp.stream_stride +
+                                            (uint64_t)(rp.sample_base + (int)s_local);
+                    rng = ptm::pcg_init(stream, rp.seed);
+                    const float ru = ptm::pcg_float(rng);
+                    const float u = ((float)i + ru) / (float)rp.width;
+                    const float rv = ptm::pcg_float(rng);
+                    const float v = ((float)j + rv) / (float)rp.height;
+                    ray = ptd::primary_ray(rp, u, v);
+                    L = ptm::mk(0, 0, 0);
+                    T = ptm::mk(1, 1, 1);
+                    depth = 0;
+                    my_w = w;
+                    alive = true;
+                    n_paths++;
+                }
+                chunk_cur += min(n, avail);
+            }
+        }
+        if (!__any(alive)) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one path segment per live lane (radiance.cuh:24-75)
+        if (alive) {
+            n_segs++;
+            const ptd::Hit h = ptd::intersect<PRUNE, STATS>(sv, ray, stk, st);
+            bool cont = false;
+            if (h.prim < 0) {
+                L = L + T * sv.bg;                          // radiance.cuh:27-30
+            } else {
+                const ptd::Surface sf = ptd::make_surface(sv, ray, h);
+                cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                depth++;
+                if (depth >= rp.max_depth) cont = false;
+            }
+            if (!cont) {
+                samples[my_w] = make_float4(L.x, L.y, L.z, 0.0f);
+                alive = false;
+            }
+        }
+    }
+    // ---- work counters (pt_counters)
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_segs);
+    unsigned long long c = STATS ? wave_sum(st.nodes) : 0ull, d = STATS ? wave_sum(st.leaves) : 0ull;
+    if (lane == 0) {
+        atomicAdd(&counters[0], a);
+        atomicAdd(&counters[1], b);
+        if (STATS) { atomicAdd(&counters[2], c); atomicAdd(&counters[3], d); }
+    }
+}
+
+// mode 0: fb = (prev + sum) * scale   (prev = accum if !first)        [final pass of pt_render]
+// mode 1: accum = prev + sum          (prev = accum if !first else 0) [intermediate pass]
+// mode 2: accum = first ? sum : accum + sum, sum started from zero    [render_progressive, main.cu:72-86]
+__global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__ samples, float* __restrict__ accum,
+                                                      float* __restrict__ fb, uint32_t npix, int spp_pass,
+                                                      int mode, int first, float scale) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    ptm::V3 sum = ptm::mk(0, 0, 0);
+    if (mode != 2 && !first) sum = ptm::mk(accum[3 * (size_t)pix], accum[3 * (size_t)pix + 1], accum[3 * (size_t)pix + 2]);
+    for (int s = 0; s < spp_pass; s++) {
+        const float4 v = samples[(size_t)s * npix + pix];
+        sum = sum + ptm::mk(v.x, v.y, v.z);                 // main.cu:47 color += radiance(...)
+    }
+    if (mode == 0) {
+        sum = sum * scale;                                  // main.cu:50 color / float(spp) == color * (1/spp)
+        fb[3 * (size_t)pix] = sum.x; fb[3 * (size_t)pix + 1] = sum.y; fb[3 * (size_t)pix + 2] = sum.z;
+    } else if (mode == 1) {
+        accum[3 * (size_t)pix] = sum.x; accum[3 * (size_t)pix + 1] = sum.y; accum[3 * (size_t)pix + 2] = sum.z;
+    } else {
+        if (!first) {
+            sum = ptm::mk(accum[3 * (size_t)pix], accum[3 * (size_t)pix + 1], accum[3 * (size_t)pix + 2]) + sum;
+        }
+        accum[3 * (size_t)pix] = sum.x; accum[3 * (size_t)pix + 1] = sum.y; accum[3 * (size_t)pix + 2] = sum.z;
+    }
+}
+
+template <bool PRUNE>
+__global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const float* __restrict__ rays, int n,
+                                                           float* __restrict__ out_tuv, int32_t* __restrict__ out_prim) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ptd::SceneView sv;
+    sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
+    sv.materials = scn.materials; sv.emission = scn.emission;
+    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
+    sv.bg = ptm::mk(0, 0, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* stk = reinterpret_cast<int32_t*>(smem) + (size_t)wave * scn.stack_cap * 64 + lane;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    ptd::Ray r;
+    r.org = ptm::mk(rays[8 * k], rays[8 * k + 1], rays[8 * k + 2]);
+    r.dir = ptm::mk(rays[8 * k + 3], rays[8 * k + 4], rays[8 * k + 5]);
+    r.tnear = rays[8 * k + 6];
+    r.tfar = rays[8 * k + 7];
+    ptd::TravStats st;
+    const ptd::Hit h = ptd::intersect<PRUNE, false>(sv, r, stk, st);
+    out_prim[k] = h.prim;
+    out_tuv[3 * k] = h.prim < 0 ? 0.0f : h.t;
+    out_tuv[3 * k + 1] = h.prim < 0 ? 0.0f : h.u;
+    out_tuv[3 * k + 2] = h.prim < 0 ? 0.0f : h.v;
+}
+
+__global__ void math_kernel(int op, const float* __restrict__ x, const float* __restrict__ y,
+                            float* __restrict__ o0, float* __restrict__ o1, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (op == 0) {
+        float s, c;
+        ptm::sincos_det(x[k], s, c);
+        o0[k] = s; o1[k] = c;
+    } else if (op == 1) {
+        o0[k] = ptm::pow_det(x[k], y[k]);
+    } else {
+        // PCG: stream = bits of x[k], seed = bits of y[k]; out0 = 1st float draw, out1 = 2nd
+        ptm::Pcg r = ptm::pcg_init((uint64_t)__builtin_bit_cast(uint32_t, x[k]), (uint64_t)__builtin_bit_cast(uint32_t, y[k]));
+        o0[k] = ptm::pcg_float(r);
+        o1[k] = ptm::pcg_float(r);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorNoDevice ? PT_ERR_NO_DEVICE : PT_ERR_DEVICE,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return PT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+        n = count;
+        return PT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+constexpr uint32_t kLdsSceneLimit = 40 * 1024;   // scenes up to this size are staged whole into LDS
+constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
+
+uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+}  // namespace
+
+struct pt_scene {
+    int device = 0;
+    int num_cus = 0;
+    size_t lds_per_block_max = 0;
+    // scene arrays
+    DevBuf<DNode> nodes;
+    DevBuf<DPrim> prims;
+    DevBuf<DNormals> normals;
+    DevBuf<DMaterial> materials;
+    DevBuf<DEmission> emission;
+    SceneDev dev{};
+    uint32_t scene_bytes = 0;
+    int bvh_depth = 0;
+    // scratch
+    DevBuf<float4> samples;
+    DevBuf<float> accum;
+    DevBuf<float> fb_tmp;
+    DevBuf<uint32_t> work_counter;
+    DevBuf<unsigned long long> counters;
+    hipStream_t last_stream = nullptr;
+    bool have_timing = false;
+    // options
+    int64_t opt_blocks_per_cu = 0;
+    int64_t opt_scratch_bytes = 0;
+    int64_t opt_force_global = 0;
+    int64_t opt_stats = 0;
+    // info of last launch
+    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0;
+    struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
+    std::vector<PassEvents> pass_events;
+    void drop_events() {
+        for (auto& pe : pass_events) { (void)hipEventDestroy(pe.t0); (void)hipEventDestroy(pe.t1); (void)hipEventDestroy(pe.r1); }
+        pass_events.clear();
+    }
+};
+
+namespace {
+
+int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
+    if (!d) return fail(PT_ERR_INVALID_ARG, "null scene description");
+    if (d->num_shapes <= 0 || !d->shapes) return fail(PT_ERR_BAD_SCENE, "scene has no shapes");
+    if (d->num_nodes != 2 * d->num_shapes - 1 || !d->nodes)
+        return fail(PT_ERR_BAD_SCENE, "BVH must have 2*num_shapes-1 nodes (bvh.cu:16-54)");
+    if (d->root < 0 || d->root >= d->num_nodes) return fail(PT_ERR_BAD_SCENE, "BVH root out of range");
+    if (d->num_materials <= 0 || !d->materials) return fail(PT_ERR_BAD_SCENE, "scene has no materials");
+    if (d->num_meshes < 0 || (d->num_meshes > 0 && !d->meshes)) return fail(PT_ERR_BAD_SCENE, "bad mesh array");
+    if (d->num_lights < 0 || (d->num_lights > 0 && !d->lights)) return fail(PT_ERR_BAD_SCENE, "bad light array");
+    for (int m = 0; m < d->num_materials; m++)
+        if (d->materials[m].type < PT_MAT_DIFFUSE || d->materials[m].type > PT_MAT_PHONG)
+            return fail(PT_ERR_BAD_SCENE, "unknown material type (scene.h:410 asserts)");
+    for (int m = 0; m < d->num_meshes; m++) {
+        const pt_mesh& me = d->meshes[m];
+        if (me.num_vertices <= 0 || me.num_faces <= 0 || !me.positions || !me.indices)
+            return fail(PT_ERR_BAD_SCENE, "empty mesh");
+        if (!me.normals) return fail(PT_ERR_BAD_SCENE, "mesh without vertex normals (required, SURVEY H5a)");
+        if (me.material_id < 0 || me.material_id >= d->num_materials) return fail(PT_ERR_BAD_SCENE, "mesh material id out of range");
+    }
+
+    // ---- primitives
+    const int N = d->num_shapes;
+    std::vector<DPrim> prims(N);
+    std::vector<DNormals> normals(N);
+    std::memset(prims.data(), 0, sizeof(DPrim) * N);
+    std::memset(normals.data(), 0, sizeof(DNormals) * N);
+    for (int i = 0; i < N; i++) {
+        const pt_shape& s = d->shapes[i];
+        DPrim& p = prims[i];
+        if (s.type == PT_SHAPE_SPHERE) {
+            if (s.material_id < 0 || s.material_id >= d->num_materials) return fail(PT_ERR_BAD_SCENE, "sphere material id out of range");
+            p.v[0] = s.center[0]; p.v[1] = s.center[1]; p.v[2] = s.center[2]; p.v[3] = s.radius;
+            p.info = (int32_t)(0x80000000u | (uint32_t)s.material_id);
+            p.light = s.area_light_id;
+        } else if (s.type == PT_SHAPE_TRIANGLE) {
+            if (s.mesh_index < 0 || s.mesh_index >= d->num_meshes) return fail(PT_ERR_BAD_SCENE, "triangle mesh index out of range");
+            const pt_mesh& me = d->meshes[s.mesh_index];
+            if (s.face_index < 0 || s.face_index >= me.num_faces) return fail(PT_ERR_BAD_SCENE, "triangle face index out of range");
+            const int32_t* idx = me.indices + 3 * (size_t)s.face_index;
+            for (int k = 0; k < 3; k++) {
+                if (idx[k] < 0 || idx[k] >= me.num_vertices) return fail(PT_ERR_BAD_SCENE, "vertex index out of range");
+                for (int c = 0; c < 3; c++) {
+                    p.v[3 * k + c] = me.positions[3 * (size_t)idx[k] + c];
+                    normals[i].n[3 * k + c] = me.normals[3 * (size_t)idx[k] + c];
+                }
+            }
+            p.info = me.material_id;
+            p.light = me.area_light_id;
+        } else {
+            return fail(PT_ERR_BAD_SCENE, "unknown shape type");
+        }
+    }
+
+    // ---- BVH: reference node pool -> inner-only nodes carrying both child boxes
+    std::vector<int32_t> inner_id(d->num_nodes, -1);
+    std::vector<DNode> nodes;
+    nodes.reserve(N > 1 ? N - 1 : 1);
+    int depth = 1;
+    int32_t root_ref;
+    std::vector<char> prim_seen(N, 0);
+    auto leaf_ok = [&](const pt_bvh_node& nd) { return nd.prim >= 0 && nd.prim < N; };
+    const pt_bvh_node& rootn = d->nodes[d->root];
+    if (rootn.prim != -1) {
+        if (!leaf_ok(rootn)) return fail(PT_ERR_BAD_SCENE, "leaf primitive id out of range");
+        root_ref = ~rootn.prim;
+        prim_seen[rootn.prim] = 1;
+    } else {
+        // DFS pre-order: a parent and its left subtree are contiguous in memory
+        struct Item { int32_t ref_node; int depth; };
+        std::vector<Item> todo;
+        todo.push_back({d->root, 1});
+        size_t visited = 0;
+        // first pass: assign ids in pre-order
+        std::vector<int32_t> order;
+        while (!todo.empty()) {
+            Item it = todo.back();
+            todo.pop_back();
+            const pt_bvh_node& nd = d->nodes[it.ref_node];
+            if (++visited > (size_t)d->num_nodes) return fail(PT_ERR_BAD_SCENE, "BVH is not a tree (cycle)");
+            if (inner_id[it.ref_node] != -1) return fail(PT_ERR_BAD_SCENE, "BVH node referenced twice");
+            if (nd.left < 0 || nd.left >= d->num_nodes || nd.right < 0 || nd.right >= d->num_nodes)
+                return fail(PT_ERR_BAD_SCENE, "BVH child index out of range");
+            inner_id[it.ref_node] = (int32_t)order.size();
+            order.push_back(it.ref_node);
+            if (it.depth + 1 > depth) depth = it.depth + 1;
+            const pt_bvh_node& ln = d->nodes[nd.left];
+            const pt_bvh_node& rn = d->nodes[nd.right];
+            if (rn.prim == -1) todo.push_back({nd.right, it.depth + 1});
+            if (ln.prim == -1) todo.push_back({nd.left, it.depth + 1});
+        }
+        nodes.resize(order.size());
+        for (size_t k = 0; k < order.size(); k++) {
+            const pt_bvh_node& nd = d->nodes[order[k]];
+            const pt_bvh_node& ln = d->nodes[nd.left];
+            const pt_bvh_node& rn = d->nodes[nd.right];
+            DNode& o = nodes[k];
+            std::memcpy(o.lmin, ln.bmin, 12); std::memcpy(o.lmax, ln.bmax, 12);
+            std::memcpy(o.rmin, rn.bmin, 12); std::memcpy(o.rmax, rn.bmax, 12);
+            for (const pt_bvh_node* ch : {&ln, &rn})
+                if (ch->prim != -1) {
+                    if (!leaf_ok(*ch)) return fail(PT_ERR_BAD_SCENE, "leaf primitive id out of range");
+                    if (prim_seen[ch->prim]) return fail(PT_ERR_BAD_SCENE, "primitive referenced by two leaves");
+                    prim_seen[ch->prim] = 1;
+                }
+            o.left = ln.prim != -1 ? ~ln.prim : inner_id[nd.left];
+            o.right = rn.prim != -1 ? ~rn.prim : inner_id[nd.right];
+            o.pad0 = o.pad1 = 0;
+        }
+        root_ref = 0;
+    }
+    if (depth - 1 > kMaxStack - 1)
+        return fail(PT_ERR_BAD_SCENE, "BVH deeper than the traversal stack (reference cap 64, scene.h:251)");
+
+    std::vector<DMaterial> mats(d->num_materials);
+    for (int m = 0; m < d->num_materials; m++) {
+        const pt_material& src = d->materials[m];
+        mats[m] = DMaterial{src.type, src.reflectance[0], src.reflectance[1], src.reflectance[2], src.eta, src.exponent, 0.0f, 0.0f};
+    }
+    std::vector<DEmission> emis(std::max(d->num_lights, 1));
+    std::memset(emis.data(), 0, sizeof(DEmission) * emis.size());
+    for (int l = 0; l < d->num_lights; l++) {
+        const pt_light& src = d->lights[l];
+        emis[l] = DEmission{src.radiance[0], src.radiance[1], src.radiance[2], src.type == PT_LIGHT_DIFFUSE_AREA ? 1 : 0};
+    }
+    if (nodes.empty()) nodes.resize(1);   // single-primitive scene: no inner nodes; keep a dummy so pointers are valid
+
+    int rc;
+    if ((rc = S->nodes.ensure(nodes.size()))) return rc;
+    if ((rc = S->prims.ensure(prims.size()))) return rc;
+    if ((rc = S->normals.ensure(normals.size()))) return rc;
+    if ((rc = S->materials.ensure(mats.size()))) return rc;
+    if ((rc = S->emission.ensure(emis.size()))) return rc;
+    HIP_TRY(hipMemcpy(S->nodes.p, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S->prims.p, prims.data(), prims.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S->normals.p, normals.data(), normals.size() * sizeof(DNormals), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S->materials.p, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(S->emission.p, emis.data(), emis.size() * sizeof(DEmission), hipMemcpyHostToDevice));
+
+    SceneDev& dv = S->dev;
+    dv.nodes = S->nodes.p; dv.prims = S->prims.p; dv.normals = S->normals.p;
+    dv.materials = S->materials.p; dv.emission = S->emission.p;
+    dv.num_nodes = (int32_t)nodes.size();
+    dv.num_prims = N;
+    dv.num_materials = d->num_materials;
+    dv.num_emission = d->num_lights;
+    dv.root_ref = root_ref;
+    dv.stack_cap = std::max(depth - 1, 1);
+    dv.bg[0] = d->background[0]; dv.bg[1] = d->background[1]; dv.bg[2] = d->background[2];
+    S->bvh_depth = depth;
+    S->scene_bytes = (uint32_t)std::min<size_t>(
+        nodes.size() * sizeof(DNode) + prims.size() * (sizeof(DPrim) + sizeof(DNormals)) + mats.size() * sizeof(DMaterial) +
+            emis.size() * sizeof(DEmission) + 64, 0xffffffffu);
+    return PT_OK;
+}
+
+LdsPlan make_plan(const pt_scene* S, bool lds_scene) {
+    LdsPlan lp{};
+    uint32_t off = 0;
+    if (lds_scene) {
+        lp.nodes_off = off; off = align16(off + (uint32_t)S->dev.num_nodes * sizeof(DNode));
+        lp.prims_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DPrim));
+        lp.normals_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DNormals));
+        lp.mats_off = off; off = align16(off + (uint32_t)S->dev.num_materials * sizeof(DMaterial));
+        lp.emis_off = off; off = align16(off + (uint32_t)std::max(S->dev.num_emission, 1) * sizeof(DEmission));
+    }
+    lp.stack_off = off;
+    off += (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
+    lp.total = off;
+    return lp;
+}
+
+using TraceFn = void (*)(SceneDev, RenderDev, LdsPlan, float4*, uint32_t*, unsigned long long*);
+
+TraceFn pick_kernel(bool lds, bool prune, bool stats) {
+    if (lds) {
+        if (prune) return stats ? trace_kernel<true, true, true> : trace_kernel<true, true, false>;
+        return stats ? trace_kernel<true, false, true> : trace_kernel<true, false, false>;
+    }
+    if (prune) return stats ? trace_kernel<false, true, true> : trace_kernel<false, true, false>;
+    return stats ? trace_kernel<false, false, true> : trace_kernel<false, false, false>;
+}
+
+struct RowSel {
+    int begin, step, count;
+};
+
+int select_rows(const pt_render_params* p, RowSel* out) {
+    int rb = p->row_begin, re = p->row_end;
+    if (rb == 0 && re == 0) re = p->height;
+    int step = p->row_stride > 1 ? p->row_stride : 1;
+    if (rb < 0 || re > p->height || rb > re) return fail(PT_ERR_INVALID_ARG, "row range outside the image");
+    int n = 0;
+    for (int j = rb; j < re; j += step) n++;
+    *out = RowSel{rb, step, n};
+    return PT_OK;
+}
+
+// mode: 0 = pt_render (fb = mean), 2 = pt_render_accumulate (accum (+)= sum)
+int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mode, hipStream_t stream) {
+    if (!S || !p || !out_dev) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (p->width <= 0 || p->height <= 0 || p->spp <= 0) return fail(PT_ERR_INVALID_ARG, "width, height and spp must be positive");
+    if (p->sample_offset < 0 || p->stream_stride < 0) return fail(PT_ERR_INVALID_ARG, "negative sample_offset / stream_stride");
+    RowSel rows;
+    int rc = select_rows(p, &rows);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(S->device));
+    if ((rc = S->counters.ensure(4))) return rc;
+    HIP_TRY(hipMemsetAsync(S->counters.p, 0, 4 * sizeof(unsigned long long), stream));
+    S->last_stream = stream;
+    S->have_timing = false;
+    S->info_passes = 0;
+    S->drop_events();
+    if (rows.count == 0) return PT_OK;
+
+    const uint64_t npix = (uint64_t)rows.count * (uint64_t)p->width;
+    if (npix > (1ull << 30)) return fail(PT_ERR_INVALID_ARG, "more than 2^30 pixels per call");
+    // samples per pass: bounded by the scratch budget and by 2^30 work items per launch
+    uint64_t scratch = S->opt_scratch_bytes > 0 ? (uint64_t)S->opt_scratch_bytes : (1ull << 30);
+    uint64_t spp_pass = std::max<uint64_t>(1, std::min<uint64_t>(scratch / (npix * sizeof(float4)), (1ull << 30) / npix));
+    spp_pass = std::min<uint64_t>(spp_pass, (uint64_t)p->spp);
+    if ((rc = S->samples.ensure(npix * spp_pass))) return rc;
+    const int n_pass = (int)(((uint64_t)p->spp + spp_pass - 1) / spp_pass);
+    if (mode == 2 && n_pass > 1)
+        return fail(PT_ERR_UNSUPPORTED, "pt_render_accumulate: spp of one call must fit the scratch budget (single pass)");
+    if (n_pass > 1 && (rc = S->accum.ensure(npix * 3))) return rc;
+    if ((rc = S->work_counter.ensure(1))) return rc;
+
+    const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
+    if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
+    const bool lds_scene = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;
+    const LdsPlan lp = make_plan(S, lds_scene);
+    if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
+    TraceFn fn = pick_kernel(lds_scene, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
+    if (lp.total > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(fn), kBlock, lp.total));
+    if (occ < 1) occ = 1;
+    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : occ;
+    S->info_occupancy = occ;
+    S->info_lds_bytes = lp.total;
+    S->info_lds_scene = lds_scene;
+
+    float* accum = mode == 2 ? out_dev : S->accum.p;
+    for (int pass = 0; pass < n_pass; pass++) {
+        const int s0 = pass * (int)spp_pass;
+        const int sn = std::min<int>((int)spp_pass, p->spp - s0);
+        RenderDev rd{};
+        std::memcpy(rd.cam_origin, p->cam_origin, 12);
+        std::memcpy(rd.cam_top_left, p->cam_top_left, 12);
+        std::memcpy(rd.cam_horizontal, p->cam_horizontal, 12);
+        std::memcpy(rd.cam_vertical, p->cam_vertical, 12);
+        rd.width = p->width; rd.height = p->height;
+        rd.row_begin = rows.begin; rd.row_step = rows.step; rd.num_rows = rows.count;
+        rd.spp_pass = sn;
+        rd.sample_base = p->sample_offset + s0;
+        rd.stream_stride = p->stream_stride > 0 ? p->stream_stride : p->spp;
+        rd.seed = p->seed;
+        rd.max_depth = p->max_depth > 0 ? p->max_depth : 50;
+        rd.rr_depth = p->rr_depth >= 0 ? p->rr_depth : 5;
+        rd.npix = (uint32_t)npix;
+        rd.total_work = (uint32_t)(npix * (uint64_t)sn);
+
+        const uint64_t blocks_needed = (rd.total_work + kBlock - 1) / kBlock;
+        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)S->num_cus * bpc, blocks_needed));
+        S->info_grid = grid;
+
+        pt_scene::PassEvents pe{};
+        HIP_TRY(hipEventCreate(&pe.t0));
+        HIP_TRY(hipEventCreate(&pe.t1));
+        HIP_TRY(hipEventCreate(&pe.r1));
+        S->pass_events.push_back(pe);
+        HIP_TRY(hipMemsetAsync(S->work_counter.p, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipEventRecord(pe.t0, stream));
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
+                           S->work_counter.p, S->counters.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(pe.t1, stream));
+
+        const bool first = pass == 0, last = pass == n_pass - 1;
+        int rmode;
+        float scale = 1.0f;
+        int rfirst;
+        if (mode == 2) {
+            // progressive: every pass adds its own partial sum; first only if sample_offset==0 and pass 0
+            rmode = 2;
+            rfirst = (first && p->sample_offset == 0) ? 1 : 0;
+        } else if (last) {
+            rmode = 0; rfirst = first ? 1 : 0; scale = 1.0f / (float)p->spp;
+        } else {
+            rmode = 1; rfirst = first ? 1 : 0;
+        }
+        hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, S->samples.p, accum,
+                           out_dev, (uint32_t)npix, sn, rmode, rfirst, scale);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(pe.r1, stream));
+        S->info_passes++;
+    }
+    S->have_timing = true;
+    return PT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int pt_api_version(void) { return PT_API_VERSION; }
+const char* pt_last_error(void) { return g_err.c_str(); }
+
+int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
+    if (!out) return fail(PT_ERR_INVALID_ARG, "null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available: the path tracer has no CPU fallback");
+    pt_scene* S = new pt_scene();
+    auto bail = [&](int rc) { pt_scene_destroy(S); return rc; };
+    if (hipGetDevice(&S->device) != hipSuccess) return bail(fail(PT_ERR_DEVICE, "hipGetDevice failed"));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S->device) != hipSuccess) return bail(fail(PT_ERR_DEVICE, "hipGetDeviceProperties failed"));
+    S->num_cus = prop.multiProcessorCount;
+    S->lds_per_block_max = prop.sharedMemPerBlock;
+    int rc = validate_and_build(desc, S);
+    if (rc) return bail(rc);
+    *out = S;
+    return PT_OK;
+}
+
+int pt_scene_destroy(pt_scene* S) {
+    if (!S) return PT_OK;
+    (void)hipSetDevice(S->device);
+    if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
+    S->nodes.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
+    S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->work_counter.release(); S->counters.release();
+    S->drop_events();
+    delete S;
+    return PT_OK;
+}
+
+int pt_render_async(pt_scene* S, const pt_render_params* p, float* fb_dev, void* hip_stream) {
+    return launch_render(S, p, fb_dev, 0, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int pt_render_accumulate(pt_scene* S, const pt_render_params* p, float* accum_dev, void* hip_stream) {
+    return launch_render(S, p, accum_dev, 2, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int pt_render(pt_scene* S, const pt_render_params* p, float* fb, int fb_on_device) {
+    if (!S || !p || !fb) return fail(PT_ERR_INVALID_ARG, "null argument");
+    if (fb_on_device) {
+        int rc = launch_render(S, p, fb, 0, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return PT_OK;
+    }
+    RowSel rows;
+    int rc = select_rows(p, &rows);
+    if (rc) return rc;
+    if (p->width <= 0) return fail(PT_ERR_INVALID_ARG, "width must be positive");
+    const size_t n = (size_t)rows.count * (size_t)p->width * 3;
+    HIP_TRY(hipSetDevice(S->device));
+    if ((rc = S->fb_tmp.ensure(n))) return rc;
+    rc = launch_render(S, p, S->fb_tmp.p, 0, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(fb, S->fb_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_get_counters(pt_scene* S, pt_counters* out) {
+    if (!S || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    HIP_TRY(hipSetDevice(S->device));
+    HIP_TRY(hipStreamSynchronize(S->last_stream));
+    if (!S->counters.p) return PT_OK;
+    unsigned long long c[4];
+    HIP_TRY(hipMemcpy(c, S->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    out->paths = c[0]; out->segments = c[1]; out->node_visits = c[2]; out->leaf_tests = c[3];
+    if (S->have_timing) {
+        double t = 0, r = 0;
+        for (auto& pe : S->pass_events) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pe.t0, pe.t1));
+            t += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, pe.t1, pe.r1));
+            r += ms;
+        }
+        out->kernel_ms = t;
+        out->resolve_ms = r;
+    }
+    return PT_OK;
+}
+
+int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
+    if (!S || !key) return fail(PT_ERR_INVALID_ARG, "null argument");
+    const std::string k(key);
+    if (k == "blocks_per_cu") S->opt_blocks_per_cu = value;
+    else if (k == "scratch_bytes") S->opt_scratch_bytes = value;
+    else if (k == "force_global") S->opt_force_global = value;
+    else if (k == "stats") S->opt_stats = value;
+    else return fail(PT_ERR_INVALID_ARG, "unknown option " + k);
+    return PT_OK;
+}
+
+int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
+    if (!S || !key || !value) return fail(PT_ERR_INVALID_ARG, "null argument");
+    const std::string k(key);
+    if (k == "grid") *value = S->info_grid;
+    else if (k == "lds_bytes") *value = S->info_lds_bytes;
+    else if (k == "lds_scene") *value = S->info_lds_scene;
+    else if (k == "passes") *value = S->info_passes;
+    else if (k == "occupancy") *value = S->info_occupancy;
+    else if (k == "num_cus") *value = S->num_cus;
+    else if (k == "bvh_depth") *value = S->bvh_depth;
+    else if (k == "scene_bytes") *value = S->scene_bytes;
+    else if (k == "num_inner_nodes") *value = S->dev.num_nodes;
+    else if (k == "device") *value = S->device;
+    else if (k == "vgprs" || k == "vgprs_pruned") {
+        hipFuncAttributes fa;
+        const bool lds = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pick_kernel(lds, k == "vgprs_pruned", S->opt_stats != 0))));
+        *value = fa.numRegs;
+    } else return fail(PT_ERR_INVALID_ARG, "unknown info key " + k);
+    return PT_OK;
+}
+
+int pt_debug_math(int op, const float* x, const float* y, float* out0, float* out1, int n) {
+    if (!x || !y || !out0 || !out1 || n < 0 || op < 0 || op > 2) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    if (n == 0) return PT_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    DevBuf<float> dx, dy, d0, d1;
+    int rc;
+    if ((rc = dx.ensure(n)) || (rc = dy.ensure(n)) || (rc = d0.ensure(n)) || (rc = d1.ensure(n))) return rc;
+    auto cleanup = [&] { dx.release(); dy.release(); d0.release(); d1.release(); };
+    hipError_t e = hipMemcpy(dx.p, x, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy.p, y, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d1.p, 0, n * sizeof(float));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, dx.p, dy.p, d0.p, d1.p, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out0, d0.p, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out1, d1.p, n * sizeof(float), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("pt_debug_math: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, float* out_tuv, int32_t* out_prim) {
+    if (!S || !rays || !out_tuv || !out_prim || n < 0) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(S->device));
+    DevBuf<float> dr, dt;
+    DevBuf<int32_t> dp;
+    int rc;
+    if ((rc = dr.ensure((size_t)n * 8)) || (rc = dt.ensure((size_t)n * 3)) || (rc = dp.ensure(n))) return rc;
+    auto cleanup = [&] { dr.release(); dt.release(); dp.release(); };
+    const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
+    hipError_t e = hipMemcpy(dr.p, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (traversal == PT_TRAVERSAL_PRUNED)
+            hipLaunchKernelGGL(intersect_kernel<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, nullptr, S->dev, dr.p, n, dt.p, dp.p);
+        else
+            hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, nullptr, S->dev, dr.p, n, dt.p, dp.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_tuv, dt.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_prim, dp.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("pt_debug_intersect: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// pt_layout.h — device-side scene layout (what pt_scene_create builds from pt_scene_desc).
+//
+// The reference walks  BVHNode(56 B) -> child BVHNodes (for their boxes) -> Shape(28 B) ->
+// TriangleMesh(80 B) -> int3 -> 3 x float3  with one dependent global load per arrow
+// (scene.h:246-301,176-224).  Here every inner node carries BOTH child boxes and child
+// references in one 64-byte record (one fetch per inner visit, leaves are not nodes at
+// all), and every primitive is pre-gathered into one 48-byte record (one fetch per leaf).
+// Topology, child order and visit order are exactly the reference's.
+#pragma once
+#include <stdint.h>
+
+namespace ptl {
+
+// Child reference: >= 0 -> index of an inner DNode; < 0 -> leaf, primitive index = ~ref.
+constexpr int32_t kDone = (int32_t)0x80000000;   // traversal sentinel (never a valid ~prim)
+
+struct alignas(16) DNode {          // 64 B
+    float lmin[3], lmax[3];         // left child's AABB
+    float rmin[3], rmax[3];         // right child's AABB
+    int32_t left, right;            // child references
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+
+// Primitive record, 48 B = 3 x float4.
+//   triangle: v = p0.xyz p1.xyz p2.xyz          sphere: v = center.xyz radius 0 0 0 0 0
+//   info    : bit 31 = sphere flag, bits 0..30 = material id
+//   light   : index into the emission table, or -1
+struct alignas(16) DPrim {
+    float v[9];
+    int32_t info;
+    int32_t light;
+    int32_t pad;
+};
+static_assert(sizeof(DPrim) == 48, "DPrim must be 48 bytes");
+
+struct alignas(16) DNormals {       // 48 B: vertex normals of a triangle (unused for spheres)
+    float n[9];
+    float pad[3];
+};
+static_assert(sizeof(DNormals) == 48, "DNormals must be 48 bytes");
+
+struct alignas(16) DMaterial {      // 32 B
+    int32_t type;
+    float r, g, b;
+    float eta, exponent;
+    float pad0, pad1;
+};
+static_assert(sizeof(DMaterial) == 32, "DMaterial must be 32 bytes");
+
+struct alignas(16) DEmission {      // 16 B: scene.lights[id] as radiance.cuh:36-41 reads it
+    float r, g, b;
+    int32_t is_area;                // light.type == DIFFUSEAREALIGHT
+};
+
+struct SceneDev {
+    const DNode* nodes;
+    const DPrim* prims;
+    const DNormals* normals;
+    const DMaterial* materials;
+    const DEmission* emission;
+    int32_t num_nodes, num_prims, num_materials, num_emission;
+    int32_t root_ref;
+    int32_t stack_cap;              // entries per lane needed (= BVH depth)
+    float bg[3];
+};
+
+struct RenderDev {
+    float cam_origin[3], cam_top_left[3], cam_horizontal[3], cam_vertical[3];
+    int32_t width, height;
+    int32_t row_begin, row_step, num_rows;   // local row r -> image row row_begin + r*row_step
+    int32_t spp_pass;               // samples traced by this launch
+    int32_t sample_base;            // absolute index of this launch's first sample (sample_offset + pass offset)
+    int32_t stream_stride;
+    uint64_t seed;
+    int32_t max_depth, rr_depth;
+    uint32_t total_work;            // num_rows*width*spp_pass
+    uint32_t npix;                  // num_rows*width
+};
+
+// LDS carve-up of the trace kernel (all offsets in bytes, 16-B aligned)
+struct LdsPlan {
+    uint32_t nodes_off, prims_off, normals_off, mats_off, emis_off, stack_off;
+    uint32_t total;
+};
+
+}  // namespace ptl

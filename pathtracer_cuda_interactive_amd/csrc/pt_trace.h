@@ -1,0 +1,347 @@
+// pt_trace.h — device functions of the path tracer: BVH traversal, primitive tests,
+// hit-record assembly, BSDF sampling/evaluation.  One ray per lane (wave64).
+//
+// Reference functions restated here (every arithmetic expression keeps the reference's
+// operand order so that results are bit-identical to the CPU oracle, see pt_math.h):
+//   intersect                        scene.h:246-301
+//   Hit (slab test)                  bbox.cuh:35-61      (1/d hoisted out of the loop: same bits)
+//   intersect_triangle               shape.cuh:188-215
+//   find_intersection_with_sphere    shape.cuh:135-186, solve_quadratic shape.cuh:110-133
+//   find_intersection_with_triangle  scene.h:176-224     (record built once, for the closest hit)
+//   sample_brdf / eval_brdf          scene.h:422-464 / 364-412
+//   schlick_fresnel, samplers        scene.h:333-357
+//   Frame / to_world                 frame.h:17-29,39-43,62-64
+#pragma once
+
+#include <float.h>
+
+#include "pt_layout.h"
+#include "pt_math.h"
+
+namespace ptd {
+
+using namespace ptm;
+using namespace ptl;
+
+struct Ray {
+    V3 org, dir;
+    float tnear, tfar;
+};
+
+struct Hit {
+    float t, u, v;
+    int32_t prim;      // -1 = miss
+};
+
+struct TravStats {
+    uint32_t nodes, leaves;
+};
+
+// Pointers to the scene arrays as the kernel sees them (LDS or global — the address
+// space is a compile-time property of each kernel instantiation).
+struct SceneView {
+    const DNode* nodes;
+    const DPrim* prims;
+    const DNormals* normals;
+    const DMaterial* materials;
+    const DEmission* emission;
+    int32_t num_emission;
+    int32_t root_ref;
+    V3 bg;
+};
+
+__device__ __forceinline__ float4 ld4(const void* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
+
+// Closest hit.  PRUNE=false visits exactly the nodes the reference visits.
+// PRUNE=true additionally skips a child whose box entry distance is beyond the current
+// closest hit; the set of candidate hits that can win is unchanged.
+// `stk` points at this lane's column of the wave's LDS stack (entry k at stk[k*64]).
+template <bool PRUNE, bool STATS>
+__device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, int32_t* stk, TravStats& st) {
+    const V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const V3 o = ray.org;
+    Hit best;
+    best.t = FLT_MAX; best.u = 0.0f; best.v = 0.0f; best.prim = -1;
+    int32_t cur = sv.root_ref;
+    int sp = 0;
+
+    while (cur != kDone) {
+        // ---- descend through inner nodes until this lane holds a leaf (or is done)
+        while (cur >= 0) {
+            const DNode* nd = sv.nodes + cur;
+            const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x
+            const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy
+            const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz
+            const float4 d = ld4(nd, 3);    // left right - -
+            if (STATS) st.nodes++;
+            // bbox.cuh:36-55 for the left box
+            float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
+            float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
+            float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
+            float ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
+            float ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
+            bool hl = ltf >= fmax2(0.0f, ltn);
+            // right box
+            float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
+            float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
+            float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
+            float rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
+            float rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
+            bool hr = rtf >= fmax2(0.0f, rtn);
+            if (PRUNE) {
+                hl = hl && !(ltn > best.t);
+                hr = hr && !(rtn > best.t);
+            }
+            const int32_t L = __builtin_bit_cast(int32_t, d.x);
+            const int32_t R = __builtin_bit_cast(int32_t, d.y);
+            if (hl && hr) {
+                // scene.h:281-289: visit the nearer box first; on a tie the right one
+                const bool left_first = ltn < rtn;
+                stk[sp * 64] = left_first ? R : L;
+                sp++;
+                cur = left_first ? L : R;
+            } else if (hl) {
+                cur = L;
+            } else if (hr) {
+                cur = R;
+            } else if (sp > 0) {
+                sp--;
+                cur = stk[sp * 64];
+            } else {
+                cur = kDone;
+            }
+        }
+        // ---- leaf: one primitive test, then pop
+        if (cur != kDone) {
+            const int32_t prim = ~cur;
+            const DPrim* pr = sv.prims + prim;
+            const float4 a = ld4(pr, 0);
+            const float4 b = ld4(pr, 1);
+            const float4 c = ld4(pr, 2);
+            if (STATS) st.leaves++;
+            const int32_t info = __builtin_bit_cast(int32_t, c.y);
+            if (info >= 0) {
+                // Möller–Trumbore, shape.cuh:188-215
+                const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
+                const V3 e1 = p1 - p0;
+                const V3 e2 = p2 - p0;
+                const V3 s1 = cross(ray.dir, e2);
+                const float divisor = dot(s1, e1);
+                if (divisor != 0.0f) {
+                    const float inv_divisor = 1.0f / divisor;
+                    const V3 s = o - p0;
+                    const float u = dot(s, s1) * inv_divisor;
+                    const V3 s2 = cross(s, e1);
+                    const float v = dot(ray.dir, s2) * inv_divisor;
+                    const float t = dot(e2, s2) * inv_divisor;
+                    if (t > ray.tnear && t < ray.tfar && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t < best.t) {
+                        best.t = t; best.u = u; best.v = v; best.prim = prim;
+                    }
+                }
+            } else {
+                // sphere, shape.cuh:135-186
+                const V3 center = mk(a.x, a.y, a.z);
+                const float radius = a.w;
+                const V3 vv = o - center;
+                const float A = dot(ray.dir, ray.dir);
+                const float B = 2.0f * dot(ray.dir, vv);
+                const float C = dot(vv, vv) - radius * radius;
+                float t0 = 0.0f, t1 = 0.0f;
+                bool ok = true;
+                if (A == 0.0f) {
+                    if (B == 0.0f) ok = false;
+                    else { t0 = -C / B; t1 = t0; }
+                } else {
+                    const float disc = B * B - 4.0f * A * C;
+                    if (disc < 0.0f) ok = false;
+                    else {
+                        const float rd = __builtin_sqrtf(disc);
+                        if (B >= 0.0f) { t0 = (-B - rd) / (2.0f * A); t1 = 2.0f * C / (-B - rd); }
+                        else { t0 = 2.0f * C / (-B + rd); t1 = (-B + rd) / (2.0f * A); }
+                    }
+                }
+                if (ok) {
+                    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+                    float t = t0;
+                    if (t1 >= ray.tnear && t1 < ray.tfar && t < ray.tnear) t = t1;
+                    if (t >= ray.tnear && t < ray.tfar && t < best.t) {
+                        best.t = t; best.u = 0.0f; best.v = 0.0f; best.prim = prim;
+                    }
+                }
+            }
+            if (sp > 0) { sp--; cur = stk[sp * 64]; }
+            else cur = kDone;
+        }
+    }
+    return best;
+}
+
+// Surface record of the closest hit (scene.h:186-217 / shape.cuh:168-180).
+struct Surface {
+    V3 p, n;             // position, shading normal
+    int32_t material, light;
+};
+
+__device__ __forceinline__ Surface make_surface(const SceneView& sv, const Ray& ray, const Hit& h) {
+    Surface s;
+    const DPrim* pr = sv.prims + h.prim;
+    const float4 a = ld4(pr, 0);
+    const float4 b = ld4(pr, 1);
+    const float4 c = ld4(pr, 2);
+    const int32_t info = __builtin_bit_cast(int32_t, c.y);
+    s.material = info & 0x7fffffff;
+    s.light = __builtin_bit_cast(int32_t, c.z);
+    if (info >= 0) {
+        const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
+        const float w = 1.0f - h.u - h.v;
+        s.p = p0 * w + p1 * h.u + p2 * h.v;
+        const DNormals* nr = sv.normals + h.prim;
+        const float4 na = ld4(nr, 0);
+        const float4 nb = ld4(nr, 1);
+        const float4 nc = ld4(nr, 2);
+        const V3 n0 = mk(na.x, na.y, na.z), n1 = mk(na.w, nb.x, nb.y), n2 = mk(nb.z, nb.w, nc.x);
+        s.n = normalize(n0 * w + n1 * h.u + n2 * h.v);
+    } else {
+        const V3 center = mk(a.x, a.y, a.z);
+        s.p = ray.org + ray.dir * h.t;
+        s.n = normalize(s.p - center);
+    }
+    return s;
+}
+
+// frame.h:17-29 + 62-64: local -> world about unit vector n (Frisvad basis)
+__device__ __forceinline__ V3 to_world_about(V3 n, V3 local) {
+    V3 fx, fy;
+    if (n.z < float(-1 + 1e-6)) {
+        fx = mk(0.0f, -1.0f, 0.0f);
+        fy = mk(-1.0f, 0.0f, 0.0f);
+    } else {
+        const float a = 1.0f / (1.0f + n.z);
+        const float b = -n.x * n.y * a;
+        fx = mk(1.0f - n.x * n.x * a, b, -n.x);
+        fy = mk(b, 1.0f - n.y * n.y * a, -n.y);
+    }
+    return fx * local.x + fy * local.y + n * local.z;
+}
+
+__device__ __forceinline__ V3 reflect_about(V3 wi, V3 n) {     // -wi + 2*dot(wi,n)*n
+    const float k = 2.0f * dot(wi, n);
+    return (-wi) + n * k;
+}
+
+__device__ __forceinline__ V3 schlick(V3 F0, float cos_theta) {   // scene.h:333-336
+    const float p5 = pow5(1.0f - cos_theta);
+    return F0 + (mk(1.0f, 1.0f, 1.0f) - F0) * p5;
+}
+
+__device__ __forceinline__ V3 sample_cos_hemisphere(float ux, float uy) {   // scene.h:338-345
+    const float phi = kTwoPi * ux;
+    const float tmp = __builtin_sqrtf(clamp01(1.0f - uy));
+    float sn, cs;
+    sincos_det(phi, sn, cs);
+    return mk(cs * tmp, sn * tmp, __builtin_sqrtf(clamp01(uy)));
+}
+
+__device__ __forceinline__ V3 sample_cos_n_hemisphere(float ux, float uy, float exponent) {   // scene.h:348-357
+    const float phi = kTwoPi * ux;
+    const float cos_theta = pow_det(uy, 1.0f / (exponent + 1.0f));
+    const float sin_theta = __builtin_sqrtf(clamp01(1.0f - cos_theta * cos_theta));
+    float sn, cs;
+    sincos_det(phi, sn, cs);
+    return mk(cs * sin_theta, sn * sin_theta, cos_theta);
+}
+
+// One bounce of radiance() after a hit (radiance.cuh:32-74): emission, BSDF sampling,
+// throughput update, next ray, Russian roulette.  Returns false when the path ends.
+__device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surface& sf, Ray& ray, Pcg& rng,
+                                                 V3& L, V3& T, int depth, int rr_depth) {
+    V3 n = sf.n;
+    const V3 wi = -ray.dir;
+    const float wi_n = dot(wi, n);
+    // radiance.cuh:35-43 — lights[] indexed by the parsed light id
+    if (sf.light >= 0 && sf.light < sv.num_emission) {
+        const float4 e = ld4(sv.emission + sf.light, 0);
+        if (__builtin_bit_cast(int32_t, e.w) != 0 && wi_n > 0.0f) L = L + T * mk(e.x, e.y, e.z);
+    }
+    if (wi_n < 0.0f) n = -n;
+
+    const DMaterial* mp = sv.materials + sf.material;
+    const float4 m0 = ld4(mp, 0);
+    const float4 m1 = ld4(mp, 1);
+    const int32_t mtype = __builtin_bit_cast(int32_t, m0.x);
+    const V3 refl = mk(m0.y, m0.z, m0.w);
+    V3 wo;
+    if (mtype == 0) {                                   // DIFFUSE: scene.h:429-433 + 370-375
+        const float ux = pcg_float(rng);
+        const float uy = pcg_float(rng);
+        wo = to_world_about(n, sample_cos_hemisphere(ux, uy));
+        const float c = fmax2(dot(wo, n), 0.0f) / kPi;
+        const V3 value = refl * c;
+        if (!(max_elem(value) > 0.0f && c > 0.0f)) return false;
+        T = T * (value * (1.0f / c));
+    } else if (mtype == 1) {                            // MIRROR: scene.h:434-438
+        wo = reflect_about(wi, n);
+        const V3 F = schlick(refl, dot(n, wo));
+        if (!(max_elem(F) > 0.0f)) return false;
+        T = T * F;
+    } else if (mtype == 2) {                            // PLASTIC: scene.h:439-454 + 379-389
+        const float q = (m1.x - 1.0f) / (m1.x + 1.0f);
+        const float F0s = q * q;
+        const V3 F = schlick(mk(F0s, F0s, F0s), dot(n, wi));
+        const float xi = pcg_float(rng);
+        if (xi <= F.x) {
+            wo = reflect_about(wi, n);
+            // weight (1,1,1): throughput *= 1
+            T = T * mk(1.0f, 1.0f, 1.0f);
+        } else {
+            const float ux = pcg_float(rng);
+            const float uy = pcg_float(rng);
+            wo = to_world_about(n, sample_cos_hemisphere(ux, uy));
+            const float c = fmax2(dot(wo, n), 0.0f) / kPi;
+            const V3 value = ((mk(1.0f, 1.0f, 1.0f) - F) * refl) * c;
+            const float pdf = (1.0f - F.x) * c;
+            if (!(max_elem(value) > 0.0f && pdf > 0.0f)) return false;
+            T = T * (value * (1.0f / pdf));
+        }
+    } else {                                            // PHONG: scene.h:455-460 + 390-408
+        const float ux = pcg_float(rng);
+        const float uy = pcg_float(rng);
+        const V3 r = reflect_about(wi, n);
+        wo = to_world_about(r, sample_cos_n_hemisphere(ux, uy, m1.y));
+        const float r_dot_wo = dot(r, wo);
+        const float n_dot_wo = dot(n, wo);
+        if (!(r_dot_wo > 0.0f && n_dot_wo > 0.0f)) return false;
+        const float resp = ((m1.y + 1.0f) / (2.0f * kPi)) * pow_det(r_dot_wo, m1.y);
+        const V3 value = refl * resp;
+        if (!(max_elem(value) > 0.0f && resp > 0.0f)) return false;
+        T = T * (value * (1.0f / resp));
+    }
+    ray.org = sf.p;
+    ray.dir = wo;
+    ray.tnear = 1e-4f;
+    ray.tfar = FLT_MAX;
+    if (depth > rr_depth) {                             // radiance.cuh:68-74
+        const float q = fmax2(0.5f, 1.0f - max_elem(T));
+        const float xi = pcg_float(rng);
+        if (xi < q) return false;
+        T = T * (1.0f / (1.0f - q));
+    }
+    return true;
+}
+
+// camera.cuh:45-50
+__device__ __forceinline__ Ray primary_ray(const RenderDev& rp, float u, float v) {
+    const V3 tl = mk(rp.cam_top_left[0], rp.cam_top_left[1], rp.cam_top_left[2]);
+    const V3 hz = mk(rp.cam_horizontal[0], rp.cam_horizontal[1], rp.cam_horizontal[2]);
+    const V3 vt = mk(rp.cam_vertical[0], rp.cam_vertical[1], rp.cam_vertical[2]);
+    const V3 og = mk(rp.cam_origin[0], rp.cam_origin[1], rp.cam_origin[2]);
+    Ray r;
+    r.org = og;
+    r.dir = normalize(((tl + hz * u) - vt * v) - og);
+    r.tnear = 0.0f;
+    r.tfar = __builtin_inff();
+    return r;
+}
+
+}  // namespace ptd

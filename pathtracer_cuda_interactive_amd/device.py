@@ -1,0 +1,124 @@
+"""Device library bindings (libpt_hip.so): the C ABI of include/pt_api.h.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is present the
+calls raise (PT_ERR_NO_DEVICE) — the product never routes through the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+from .ctypes_defs import (PT_OK, PT_TRAVERSAL_DEFAULT, PtCounters, PtError, PtRenderParams, PtSceneDesc)
+
+_lib = None
+
+EXPORTS = [
+    "pt_api_version", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_async",
+    "pt_render_accumulate", "pt_get_counters", "pt_scene_set_option", "pt_scene_get_info", "pt_debug_math",
+    "pt_debug_intersect",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.HIP_LIB
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -m pathtracer_cuda_interactive_amd._build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(path)
+        vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.pt_api_version.restype = C.c_int
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_scene_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(vp)]
+        L.pt_scene_destroy.argtypes = [vp]
+        L.pt_render.argtypes = [vp, C.POINTER(PtRenderParams), vp, C.c_int]
+        L.pt_render_async.argtypes = [vp, C.POINTER(PtRenderParams), vp, vp]
+        L.pt_render_accumulate.argtypes = [vp, C.POINTER(PtRenderParams), vp, vp]
+        L.pt_get_counters.argtypes = [vp, C.POINTER(PtCounters)]
+        L.pt_scene_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.pt_scene_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+        L.pt_debug_math.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
+        L.pt_debug_intersect.argtypes = [vp, fp, C.c_int, C.c_int, fp, ip]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != PT_OK:
+        raise PtError(rc, lib().pt_last_error().decode())
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class DeviceScene:
+    """A scene resident on the current HIP device (pt_scene*)."""
+
+    def __init__(self, desc):
+        h = C.c_void_p()
+        _check(lib().pt_scene_create(C.byref(desc), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _check(lib().pt_scene_set_option(self._h, key.encode(), int(value)))
+
+    def info(self, key):
+        v = C.c_int64()
+        _check(lib().pt_scene_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def render(self, params, traversal=None):
+        """Blocking render into a new host array [rows, W, 3] float32."""
+        p = params.copy()
+        if traversal is not None:
+            p.traversal = traversal
+        img = np.empty((p.num_rows(), p.width, 3), dtype=np.float32)
+        _check(lib().pt_render(self._h, C.byref(p), img.ctypes.data_as(C.c_void_p), 0))
+        return img
+
+    def render_into(self, params, dev_ptr, stream=None, traversal=None):
+        """Asynchronous render into device memory (e.g. a torch tensor's data_ptr()) on a HIP stream."""
+        p = params.copy()
+        if traversal is not None:
+            p.traversal = traversal
+        _check(lib().pt_render_async(self._h, C.byref(p), C.c_void_p(dev_ptr), C.c_void_p(stream or 0)))
+
+    def accumulate_into(self, params, dev_ptr, stream=None):
+        _check(lib().pt_render_accumulate(self._h, C.byref(params), C.c_void_p(dev_ptr), C.c_void_p(stream or 0)))
+
+    def counters(self):
+        c = PtCounters()
+        _check(lib().pt_get_counters(self._h, C.byref(c)))
+        return c
+
+    def intersect(self, rays, traversal=PT_TRAVERSAL_DEFAULT):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        tuv = np.zeros((rays.shape[0], 3), dtype=np.float32)
+        prim = np.zeros(rays.shape[0], dtype=np.int32)
+        _check(lib().pt_debug_intersect(self._h, _fp(rays), rays.shape[0], traversal, _fp(tuv),
+                                        prim.ctypes.data_as(C.POINTER(C.c_int32))))
+        return tuv, prim
+
+
+def debug_math(op, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)
+    o0 = np.zeros_like(x)
+    o1 = np.zeros_like(x)
+    _check(lib().pt_debug_math(op, _fp(x), _fp(y), _fp(o0), _fp(o1), x.size))
+    return o0, o1
