@@ -186,8 +186,12 @@ int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
 
 /* Deterministic fp32 helpers evaluated ON THE DEVICE, exported so tests can
  * pin device arithmetic against the CPU oracle bit-for-bit.
- * op: 0 sincos(x)->(sin,cos)  1 powf(x,y)  2 pcg32 floats (x = stream as float bits ignored; see impl) */
+ * op: 0 sincos(x)->(out0=sin,out1=cos)   1 powf(x,y)->out0
+ *     2 pcg32: stream = bit pattern of x, seed = bit pattern of y -> first two float draws */
 int pt_debug_math(int op, const float* x, const float* y, float* out0, float* out1, int n);
+/* Same functions (the very same source, csrc/pt_math.h) evaluated by the HOST half of the
+ * library: lets CPU-only tests pin the shared arithmetic header without a GPU. */
+int pt_debug_math_host(int op, const float* x, const float* y, float* out0, float* out1, int n);
 
 /* Closest-hit query for explicit rays (tests / per-ray KATs).
  * rays: n x {org[3], dir[3], tnear, tfar}; out: n x {t,u,v} and prim id (-1 = miss). */

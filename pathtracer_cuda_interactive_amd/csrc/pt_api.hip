@@ -770,6 +770,23 @@ int pt_debug_math(int op, const float* x, const float* y, float* out0, float* ou
     return PT_OK;
 }
 
+int pt_debug_math_host(int op, const float* x, const float* y, float* out0, float* out1, int n) {
+    if (!x || !y || !out0 || !out1 || n < 0 || op < 0 || op > 2) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    for (int k = 0; k < n; k++) {
+        if (op == 0) {
+            ptm::sincos_det(x[k], out0[k], out1[k]);
+        } else if (op == 1) {
+            out0[k] = ptm::pow_det(x[k], y[k]);
+            out1[k] = 0.0f;
+        } else {
+            ptm::Pcg r = ptm::pcg_init((uint64_t)__builtin_bit_cast(uint32_t, x[k]), (uint64_t)__builtin_bit_cast(uint32_t, y[k]));
+            out0[k] = ptm::pcg_float(r);
+            out1[k] = ptm::pcg_float(r);
+        }
+    }
+    return PT_OK;
+}
+
 int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, float* out_tuv, int32_t* out_prim) {
     if (!S || !rays || !out_tuv || !out_prim || n < 0) return fail(PT_ERR_INVALID_ARG, "bad argument");
     if (n == 0) return PT_OK;

@@ -16,7 +16,7 @@ _lib = None
 EXPORTS = [
     "pt_api_version", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_async",
     "pt_render_accumulate", "pt_get_counters", "pt_scene_set_option", "pt_scene_get_info", "pt_debug_math",
-    "pt_debug_intersect",
+    "pt_debug_intersect", "pt_debug_math_host",
 ]
 
 
@@ -42,6 +42,7 @@ def lib():
         L.pt_scene_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
         L.pt_debug_math.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
         L.pt_debug_intersect.argtypes = [vp, fp, C.c_int, C.c_int, fp, ip]
+        L.pt_debug_math_host.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
         _lib = L
     return _lib
 
@@ -115,10 +116,12 @@ class DeviceScene:
         return tuv, prim
 
 
-def debug_math(op, x, y=None):
+def debug_math(op, x, y=None, host=False):
+    """op 0: sincos, 1: powf, 2: pcg32 (stream/seed = bit patterns of x/y).  host=True runs the host build of pt_math.h."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = x if y is None else np.ascontiguousarray(y, dtype=np.float32)
     o0 = np.zeros_like(x)
     o1 = np.zeros_like(x)
-    _check(lib().pt_debug_math(op, _fp(x), _fp(y), _fp(o0), _fp(o1), x.size))
+    fn = lib().pt_debug_math_host if host else lib().pt_debug_math
+    _check(fn(op, _fp(x), _fp(y), _fp(o0), _fp(o1), x.size))
     return o0, o1

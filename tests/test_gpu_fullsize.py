@@ -1,0 +1,63 @@
+"""BASELINE.json's full-size configs on the GPU, checked through size-independent properties
+(the oracle needs ~minutes for whole frames, so whole-frame equality is replaced by: exact == pruned
+traversal, shards tile the frame, determinism, spot pixels against the oracle, work counters)."""
+import numpy as np
+import pytest
+from conftest import assert_bit_equal, load_scene
+
+from pathtracer_cuda_interactive_amd import PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED
+from pathtracer_cuda_interactive_amd import device as dev
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {          # BASELINE.json configs[0..2]
+    "scene1": (640, 480, 16),
+    "cbox": (640, 480, 64),
+    "bunny": (640, 480, 64),
+}
+SURVEY_SEGS_PER_PATH = {"scene1": 2.097, "cbox": 3.553, "bunny": 2.264}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_fullsize_config_properties(oracle, name):
+    w, h, spp = CONFIGS[name]
+    hs, d = load_scene(name)
+    p = hs.render_params(w, h, spp)
+    ds = dev.DeviceScene(d)
+    try:
+        exact = ds.render(p, traversal=PT_TRAVERSAL_EXACT)
+        c = ds.counters()
+        assert c.paths == w * h * spp
+        assert abs(c.segments / c.paths - SURVEY_SEGS_PER_PATH[name]) < 0.02      # SURVEY §8d work counters
+        assert np.isfinite(exact).all() and exact.min() >= 0
+        # (1) closest-t pruning does not change a single bit of the frame
+        pruned = ds.render(p, traversal=PT_TRAVERSAL_PRUNED)
+        assert ds.counters().segments == c.segments
+        assert_bit_equal(pruned, exact, name + " pruned==exact")
+        # (2) deterministic across launches (lane refill order does not leak into the image)
+        assert_bit_equal(ds.render(p, traversal=PT_TRAVERSAL_EXACT), exact, name + " rerun")
+        # (3) 8 interleaved row shards (the multi-GPU decomposition) tile the frame exactly
+        out = np.zeros_like(exact)
+        for r in range(8):
+            q = p.copy()
+            q.row_begin, q.row_end, q.row_stride = r, h, 8
+            out[r::8] = ds.render(q)
+        assert_bit_equal(out, exact, name + " shards")
+        # (4) scene staged in LDS vs read from global memory
+        ds.set_option("force_global", 1)
+        assert_bit_equal(ds.render(p), exact, name + " global")
+        ds.set_option("force_global", 0)
+        # (5) spot pixels against the oracle at full spp (bounded CPU work)
+        rng = np.random.default_rng(9)
+        n = 96 if name != "bunny" else 48
+        xy = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], axis=1).astype(np.int32)
+        xy[0] = (w // 2, h // 2)
+        xy[1] = (0, 0)
+        want, _ = oracle.render_pixels(d, p, xy)
+        got = exact[xy[:, 1], xy[:, 0]]
+        assert np.abs(got - want).max() <= 1e-4
+        assert_bit_equal(got, want, name + " spot pixels")
+        if name in ("scene1", "cbox"):
+            assert (exact[0, 0] == np.float32(0.5)).all()        # corner pixel sees only the 0.5 background
+    finally:
+        ds.close()

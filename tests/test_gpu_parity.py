@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path (through the C ABI, libpt_hip.so) against the CPU oracle and the
+committed golden vectors.  Bar: BIT-EXACT fp32 (stronger than BASELINE.json's 1e-4 L-inf, which is
+asserted as well) — any 1-ulp difference would be amplified into different paths."""
+import glob
+import os
+
+import numpy as np
+import pytest
+from conftest import GOLDEN, assert_bit_equal, load_scene, random_scene
+from test_golden_vectors import parse_image_name
+
+from pathtracer_cuda_interactive_amd import (PT_ERR_BAD_SCENE, PT_ERR_INVALID_ARG, PT_ERR_UNSUPPORTED, PT_MAT_DIFFUSE,
+                                             PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED, HostScene, PtError)
+from pathtracer_cuda_interactive_amd import device as dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # BASELINE.json: per-channel L-inf vs the oracle on identical PCG seeds
+IMAGES = sorted(glob.glob(os.path.join(GOLDEN, "images", "*.npy")))
+TRAVERSALS = [PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED]
+
+
+@pytest.fixture(scope="module")
+def dscenes():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            _, d = load_scene(name)
+            cache[name] = dev.DeviceScene(d)
+        return cache[name]
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+@pytest.mark.parametrize("path", IMAGES, ids=os.path.basename)
+@pytest.mark.parametrize("trav", TRAVERSALS)
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_device_reproduces_golden_image(dscenes, path, trav, force_global):
+    name, w, h, spp = parse_image_name(path)
+    hs, _ = load_scene(name)
+    ds = dscenes(name)
+    ds.set_option("force_global", force_global)
+    img = ds.render(hs.render_params(w, h, spp), traversal=trav)
+    ds.set_option("force_global", 0)
+    want = np.load(path)
+    assert np.abs(img - want).max() <= TOL
+    assert_bit_equal(img, want, f"{name} trav={trav} global={force_global}")
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("cbox", 96, 72, 9), ("scene1", 80, 60, 12), ("scene1_phong", 64, 64, 10),
+                                          ("teapot", 50, 40, 3), ("bunny", 40, 30, 2), ("tetrahedron", 33, 17, 5)])
+def test_device_matches_live_oracle(oracle, dscenes, name, w, h, spp):
+    hs, d = load_scene(name)
+    p = hs.render_params(w, h, spp, seed=77)
+    want, cnt = oracle.render(d, p)
+    ds = dscenes(name)
+    ds.set_option("stats", 1)
+    img = ds.render(p, traversal=PT_TRAVERSAL_EXACT)
+    c = ds.counters()
+    ds.set_option("stats", 0)
+    assert_bit_equal(img, want, name)
+    # work counters agree with the oracle's: same paths, same segments, same node visits / primitive tests
+    assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
+    assert c.node_visits == cnt.inner_pops and c.leaf_tests == cnt.leaf_tri + cnt.leaf_sphere
+    img2 = ds.render(p, traversal=PT_TRAVERSAL_PRUNED)
+    assert_bit_equal(img2, want, name + " pruned")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_all_materials(oracle, seed):
+    hs = random_scene(seed, n_tris=24 + 7 * seed, n_spheres=3 + seed % 3)
+    d = hs.finalize()
+    p = hs.render_params(56, 40, 6, seed=1000 + seed)
+    want, cnt = oracle.render(d, p)
+    assert cnt.term_absorb > 0 and cnt.emit > 0 and cnt.term_rr + cnt.term_miss > 0
+    ds = dev.DeviceScene(d)
+    try:
+        for trav in TRAVERSALS:
+            for fg in (0, 1):
+                ds.set_option("force_global", fg)
+                assert_bit_equal(ds.render(p, traversal=trav), want, f"seed {seed} trav {trav} global {fg}")
+    finally:
+        ds.close()
+
+
+def test_row_ranges_and_strides_tile_the_image(oracle, dscenes):
+    hs, d = load_scene("cbox")
+    ds = dscenes("cbox")
+    p = hs.render_params(48, 37, 5)
+    full = ds.render(p)
+    assert_bit_equal(full, oracle.render(d, p)[0], "full")
+    # contiguous bands
+    parts = []
+    for rb, re in [(0, 10), (10, 11), (11, 37)]:
+        q = p.copy()
+        q.row_begin, q.row_end = rb, re
+        parts.append(ds.render(q))
+    assert_bit_equal(np.concatenate(parts, axis=0), full, "bands")
+    # interleaved rows, as the multi-GPU sharding uses them (rank r of n renders rows r, r+n, ...)
+    n = 4
+    out = np.zeros_like(full)
+    for r in range(n):
+        q = p.copy()
+        q.row_begin, q.row_end, q.row_stride = r, p.height, n
+        part = ds.render(q)
+        assert part.shape[0] == len(range(r, p.height, n))
+        assert_bit_equal(part, oracle.render(d, q)[0], f"stride rank {r}")
+        out[r::n] = part
+    assert_bit_equal(out, full, "interleaved")
+    # empty selection
+    q = p.copy()
+    q.row_begin, q.row_end = 5, 5
+    assert ds.render(q).shape == (0, 48, 3)
+
+
+def test_multi_pass_equals_single_pass(dscenes):
+    hs, _ = load_scene("cbox")
+    ds = dscenes("cbox")
+    p = hs.render_params(40, 30, 11)
+    one = ds.render(p)
+    assert ds.info("passes") == 1
+    ds.set_option("scratch_bytes", 40 * 30 * 16 * 3)      # room for 3 samples per pass -> 4 passes
+    many = ds.render(p)
+    assert ds.info("passes") == 4
+    ds.set_option("scratch_bytes", 0)
+    assert_bit_equal(many, one, "multi-pass")
+
+
+def test_sample_offset_and_stream_stride_address_absolute_samples(oracle, dscenes):
+    """Samples [4,8) of an 8-spp stream layout rendered alone == the oracle doing the same."""
+    hs, d = load_scene("scene1")
+    ds = dscenes("scene1")
+    p = hs.render_params(32, 24, 4)
+    p.sample_offset, p.stream_stride = 4, 8
+    assert_bit_equal(ds.render(p), oracle.render(d, p)[0], "offset")
+    p0 = hs.render_params(32, 24, 4)
+    assert np.abs(ds.render(p) - ds.render(p0)).max() > 0
+
+
+def test_progressive_accumulation_matches_render_progressive_semantics(oracle, dscenes):
+    """pt_render_accumulate == render_progressive (main.cu:64-89): accum (=|+=) sum of the call's new samples."""
+    import torch
+    hs, d = load_scene("cbox")
+    ds = dscenes("cbox")
+    W, H, total = 40, 30, 6
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    acc.fill_(123.0)                                  # must be overwritten by the first call
+    want = None
+    for k, (off, n) in enumerate([(0, 2), (2, 3), (5, 1)]):
+        p = hs.render_params(W, H, n)
+        p.sample_offset, p.stream_stride = off, total
+        ds.accumulate_into(p, acc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        part, _ = oracle.render(d, p, accumulate=True)
+        want = part if k == 0 else (want + part).astype(np.float32)
+    torch.cuda.synchronize()
+    assert_bit_equal(acc.cpu().numpy(), want, "progressive")
+    # ... and it converges to the offline image (different summation order: tolerance, not bits)
+    off = ds.render(hs.render_params(W, H, total))
+    np.testing.assert_allclose(acc.cpu().numpy() / total, off, rtol=1e-5, atol=1e-6)
+
+
+def test_async_render_into_torch_tensor_on_side_stream(oracle, dscenes):
+    import torch
+    hs, d = load_scene("scene1")
+    ds = dscenes("scene1")
+    p = hs.render_params(64, 32, 3)
+    st = torch.cuda.Stream()
+    fb = torch.empty((32, 64, 3), dtype=torch.float32, device="cuda")
+    with torch.cuda.stream(st):
+        ds.render_into(p, fb.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert_bit_equal(fb.cpu().numpy(), oracle.render(d, p)[0], "async")
+    c = ds.counters()
+    assert c.paths == 64 * 32 * 3 and c.kernel_ms > 0
+
+
+@pytest.mark.parametrize("max_depth,rr_depth", [(1, 5), (2, 0), (7, 2), (50, 49)])
+def test_depth_limits(oracle, dscenes, max_depth, rr_depth):
+    hs, d = load_scene("cbox")
+    p = hs.render_params(32, 24, 4)
+    p.max_depth, p.rr_depth = max_depth, rr_depth
+    want, cnt = oracle.render(d, p)
+    if max_depth <= 2:
+        assert cnt.term_maxdepth > 0
+    assert_bit_equal(dscenes("cbox").render(p), want, f"depth {max_depth}/{rr_depth}")
+
+
+def test_edge_sizes(oracle, dscenes):
+    hs, d = load_scene("cbox")
+    ds = dscenes("cbox")
+    for w, h, spp in [(1, 1, 1), (1, 7, 2), (65, 1, 1), (3, 3, 70)]:
+        p = hs.render_params(w, h, spp)
+        assert_bit_equal(ds.render(p), oracle.render(d, p)[0], f"{w}x{h}x{spp}")
+
+
+def test_single_primitive_scenes(oracle):
+    """Root is a leaf: no inner nodes at all (bvh.cu:18-25)."""
+    for kind in ("sphere", "triangle"):
+        hs = HostScene()
+        hs.set_camera((0, 0, 3), (0, 0, 0), (0, 1, 0), 45, 24, 24, 4)
+        m = hs.add_material(PT_MAT_DIFFUSE, (0.7, 0.6, 0.5))
+        if kind == "sphere":
+            hs.add_sphere((0, 0, 0), 1.0, m, radiance=(1, 2, 3))
+        else:
+            hs.add_mesh(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32), m)
+        d = hs.finalize()
+        assert d.num_nodes == 1
+        p = hs.render_params()
+        want, cnt = oracle.render(d, p)
+        assert cnt.closer_hits > 0
+        ds = dev.DeviceScene(d)
+        try:
+            for trav in TRAVERSALS:
+                assert_bit_equal(ds.render(p, traversal=trav), want, kind)
+        finally:
+            ds.close()
+
+
+def test_axis_aligned_rays_and_degenerate_geometry(oracle):
+    """Rays with exactly-zero direction components (1/0 = inf, 0*inf = NaN in the slab test, bbox.cuh:36-38),
+    origins lying exactly on box planes, a zero-area triangle and a zero-radius sphere."""
+    hs = HostScene()
+    m = hs.add_material(PT_MAT_DIFFUSE, (0.8, 0.8, 0.8))
+    quad = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    hs.add_mesh(quad, np.array([[0, 1, 2], [0, 2, 3]], np.int32), m)
+    hs.add_mesh(quad + np.float32([0, 0, -1]), np.array([[0, 1, 2], [0, 2, 3]], np.int32), m)
+    hs.add_mesh(np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1]], np.float32), np.array([[0, 1, 2]], np.int32), m,
+                normals=np.array([[0, 0, 1]] * 3, np.float32))                      # zero-area triangle
+    hs.add_sphere((0.5, 0.5, 0.5), 0.0, m)                                          # zero-radius sphere
+    hs.add_sphere((-0.5, 0.25, 0.5), 0.25, m)
+    d = hs.finalize()
+    rays = []
+    for ox in (-1.0, -0.5, 0.0, 0.25, 1.0):            # origins on the planes x=-1, 0, 1 of the boxes
+        for oy in (-1.0, 0.0, 0.5, 1.0):
+            for dz in (-1.0, 1.0):
+                rays.append([ox, oy, 2.0 * -dz, 0.0, 0.0, dz, 0.0, np.inf])
+                rays.append([ox, oy, 0.0, 0.0, 0.0, dz, 1e-4, 3.4e38])
+            rays.append([ox, -3.0, 0.5, 0.0, 1.0, 0.0, 0.0, np.inf])               # grazing along y inside plane x=ox
+            rays.append([-3.0, oy, 0.5, 1.0, 0.0, 0.0, 0.0, np.inf])
+            rays.append([ox, oy, 0.5, -0.0, 0.0, -1.0, 0.0, np.inf])               # negative zero component
+    rays = np.array(rays, dtype=np.float32)
+    tuv, prim = oracle.intersect(d, rays)
+    assert (prim >= 0).sum() > 20
+    ds = dev.DeviceScene(d)
+    try:
+        for trav in TRAVERSALS:
+            t2, p2 = ds.intersect(rays, traversal=trav)
+            assert (p2 == prim).all(), trav
+            assert_bit_equal(t2, tuv, f"degenerate trav {trav}")
+        hs.set_camera((0, 0, 4), (0, 0, 0), (0, 1, 0), 40, 33, 33, 3)       # odd size: centre pixel looks straight down -z
+        p = hs.render_params()
+        assert_bit_equal(ds.render(p), oracle.render(d, p)[0], "degenerate render")
+    finally:
+        ds.close()
+
+
+def test_deep_unbalanced_bvh_uses_the_lds_stack(oracle):
+    """A hand-made 'caterpillar' BVH 40 levels deep (the reference's stack cap is 64, scene.h:251)."""
+    import ctypes as C
+
+    from pathtracer_cuda_interactive_amd.ctypes_defs import PtBvhNode, PtSceneDesc
+    n = 40
+    hs = HostScene()
+    hs.set_camera((0, 0, 6), (0, 0, 0), (0, 1, 0), 60, 40, 24, 3)
+    m = hs.add_material(PT_MAT_DIFFUSE, (0.6, 0.7, 0.8))
+    for k in range(n):
+        hs.add_sphere((-4 + 8 * k / (n - 1), np.sin(k) * 1.5, np.cos(k * 1.7)), 0.3, m)
+    d = hs.finalize()
+    leaves = {int(nd["prim"]): nd for nd in hs.nodes_array() if nd["prim"] != -1}
+    nodes = (PtBvhNode * (2 * n - 1))()
+    for k in range(n):                                     # leaves 0..n-1
+        nodes[k] = PtBvhNode(tuple(leaves[k]["bmin"]), tuple(leaves[k]["bmax"]), -1, -1, k)
+    prev = 0
+    for k in range(1, n):                                  # inner node n-1+k = (chain so far, leaf k)
+        a, b = nodes[prev], nodes[k]
+        lo = tuple(min(a.bmin[i], b.bmin[i]) for i in range(3))
+        hi = tuple(max(a.bmax[i], b.bmax[i]) for i in range(3))
+        nodes[n - 1 + k] = PtBvhNode(lo, hi, prev, k, -1)
+        prev = n - 1 + k
+    d2 = PtSceneDesc()
+    C.memmove(C.byref(d2), C.byref(d), C.sizeof(PtSceneDesc))
+    d2.nodes, d2.num_nodes, d2.root = nodes, 2 * n - 1, prev
+    p = hs.render_params()
+    want, cnt = oracle.render(d2, p)
+    ds = dev.DeviceScene(d2)
+    try:
+        assert ds.info("bvh_depth") == n
+        for trav in TRAVERSALS:
+            assert_bit_equal(ds.render(p, traversal=trav), want, "caterpillar")
+    finally:
+        ds.close()
+
+
+def test_invalid_descriptors_and_params_return_status_codes(dscenes):
+    import ctypes as C
+
+    from pathtracer_cuda_interactive_amd.ctypes_defs import PtSceneDesc
+    hs, d = load_scene("cbox")
+
+    def broken(**kw):
+        b = PtSceneDesc()
+        C.memmove(C.byref(b), C.byref(d), C.sizeof(PtSceneDesc))
+        for k, v in kw.items():
+            setattr(b, k, v)
+        return b
+    for bad in (broken(root=d.num_nodes), broken(num_nodes=d.num_nodes - 1), broken(num_shapes=0), broken(num_materials=0)):
+        with pytest.raises(PtError) as e:
+            dev.DeviceScene(bad)
+        assert e.value.status == PT_ERR_BAD_SCENE and len(str(e.value)) > 20
+    ds = dscenes("cbox")
+    for field, val in (("spp", 0), ("width", 0), ("row_end", 10 ** 6), ("traversal", 9), ("sample_offset", -1)):
+        p = hs.render_params(16, 16, 2)
+        setattr(p, field, val)
+        with pytest.raises(PtError) as e:
+            ds.render(p)
+        assert e.value.status == PT_ERR_INVALID_ARG, field
+    with pytest.raises(PtError) as e:
+        ds.set_option("no_such_option", 1)
+    assert e.value.status == PT_ERR_INVALID_ARG
+    import torch
+    buf = torch.zeros(16 * 16 * 3, device="cuda")
+    ds.set_option("scratch_bytes", 16 * 16 * 16)
+    p = hs.render_params(16, 16, 5)
+    with pytest.raises(PtError) as e:
+        ds.accumulate_into(p, buf.data_ptr())
+    ds.set_option("scratch_bytes", 0)
+    assert e.value.status == PT_ERR_UNSUPPORTED

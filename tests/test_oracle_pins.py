@@ -1,0 +1,68 @@
+"""Pins the CPU oracle (and the host scene pipeline that feeds it) to the values SURVEY.md §8c
+recorded from a host build of the reference's own headers: PCG known-answer vectors, BVH topology,
+image statistics / pixel bit patterns / SHA-256 under the reference's per-pixel-sequential RNG use
+(main.cu:36-47) with glibc math.  These are the only externally recorded outputs of the reference
+algorithm that exist (the reference ships no tests)."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+from conftest import GOLDEN, load_scene
+
+PINS = json.load(open(os.path.join(GOLDEN, "pins.json")))
+
+
+@pytest.mark.parametrize("kat", PINS["pcg"], ids=lambda k: f"stream{k['stream']}")
+def test_pcg_known_answers(oracle, kat):
+    u, f, (state, inc) = oracle.pcg(kat["stream"], kat["seed"], 4)
+    assert state == kat["state"] and inc == kat["inc"]
+    assert [int(x) for x in u] == kat["u32"]
+    if "f32" in kat:
+        np.testing.assert_allclose(f, np.array(kat["f32"], dtype=np.float32), rtol=0, atol=1e-9)
+        assert (f >= 0).all() and (f < 1).all()
+
+
+@pytest.mark.parametrize("name", sorted(PINS["survey_topology"]))
+def test_scene_topology_matches_survey(name):
+    hs, d = load_scene(name)
+    want = PINS["survey_topology"][name]
+    got = {"shapes": d.num_shapes, "meshes": d.num_meshes, "materials": d.num_materials, "lights": d.num_lights,
+           "nodes": d.num_nodes, "root": d.root, "depth": hs.bvh_depth}
+    for k, v in want.items():
+        assert got[k] == v, f"{name}.{k}: {got[k]} != {v}"
+    assert d.num_nodes == 2 * d.num_shapes - 1 and d.root == d.num_nodes - 1
+
+
+@pytest.mark.parametrize("name", ["scene1", "cbox"])
+def test_image_matches_survey_recording(oracle, name):
+    """Oracle in 'host semantics' mode == what the reference's headers computed, bit for bit."""
+    want = PINS["survey_images_libm_per_pixel_rng"][name]
+    hs, d = load_scene(name)
+    p = hs.render_params(want["w"], want["h"], want["spp"], seed=1984)
+    img, cnt = oracle.render(d, p, math_mode=oracle.MATH_LIBM, rng_mode=oracle.RNG_PER_PIXEL)
+    px = [format(struct.unpack("<I", struct.pack("<f", float(v)))[0], "08x") for v in img[240, 320]]
+    assert px == want["px_320_240_hex"]
+    assert hashlib.sha256(img.tobytes()).hexdigest()[:16] == want["sha256_16"]
+    assert abs(float(img.astype(np.float64).mean()) - want["mean"]) < 1e-8
+    assert abs(float(img.max()) - want["max"]) < 1e-6
+    assert (img[0, 0] == np.float32(0.5)).all()          # background pixel
+    c = PINS["survey_counters"][name]
+    segs = cnt.segments
+    assert abs(segs / cnt.paths - c["segs_per_path"]) < 2e-3
+    assert abs(cnt.inner_pops / segs - c["inner_per_seg"]) < 6e-3
+    assert abs((cnt.leaf_tri + cnt.leaf_sphere) / segs - c["leaf_per_seg"]) < 6e-3
+    assert cnt.max_stack == c["max_stack"]
+    assert abs(cnt.rng_draws / cnt.paths - c["rng_per_path"]) < 6e-3
+    assert abs(cnt.bytes_per_segment() - c["bytes_per_seg"]) < 1.0     # SURVEY §8d algorithmic bytes/segment
+    assert cnt.term_maxdepth == 0 and cnt.stack_overflow == 0
+
+
+def test_thread_count_does_not_change_the_image(oracle):
+    hs, d = load_scene("cbox")
+    p = hs.render_params(48, 36, 3)
+    a, _ = oracle.render(d, p, threads=1)
+    b, _ = oracle.render(d, p, threads=5)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
