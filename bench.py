@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (ray segments = intersect() calls per second) and ms/frame of the
+path-tracing hot path on BASELINE.json's metric config — cbox 640x480 spp=64 on one MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cbox|bunny|scene1] [--traversal exact|pruned]
+
+One "step" = one full frame: trace kernel(s) + ordered resolve (+ gather to rank 0 when N>1).
+N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling — the frame stays 640x480 and the
+sample count grows to 64*N, rows are interleaved over ranks (rank r: rows r, r+N, ...), so every GPU traces
+the same 19.66 M paths as the 1-GPU run; the row bands are gathered to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  `value` is the whole-job rate with the scene already resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+# BASELINE.json configs; bytes_per_segment = SURVEY §8d algorithmic bytes of the reference layout
+# (60 B/inner pop + 120 B/triangle leaf + 32 B/sphere leaf + 60 B/closer triangle hit + 40 B shade), from the
+# reference-traversal work counters (re-derived by the oracle in tests/test_oracle_pins.py for scene1/cbox).
+WORKLOADS = {
+    "cbox":   {"w": 640, "h": 480, "spp": 64, "bytes_per_segment": 1455.0, "label": "scenes/cbox/cbox.xml 640x480 spp=64 (BASELINE.json configs[1])"},
+    "bunny":  {"w": 640, "h": 480, "spp": 64, "bytes_per_segment": 3625.0, "label": "scenes/bunny/bunny.xml 640x480 spp=64 (BASELINE.json configs[2])"},
+    "scene1": {"w": 640, "h": 480, "spp": 16, "bytes_per_segment": 240.0, "label": "scenes/spheres/scene1.xml 640x480 spp=16 (BASELINE.json configs[0])"},
+}
+
+
+def cpu_baseline(desc, params, name):
+    """The oracle (CPU port of the same algorithm) timed on this box's host cores — reported, never shipped."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_binding as ob
+    ob.build()
+    t0 = time.perf_counter()
+    if name == "bunny":            # ~0.34 Mpaths/s/core: bound the sample to 1/16 of the frame (every 16th row)
+        q = params.copy()
+        q.row_begin, q.row_end, q.row_stride = 0, params.height, 16
+        sample = "every 16th row of the frame (30 rows x 640 px x 64 spp)"
+    else:
+        q = params
+        sample = f"full frame {params.width}x{params.height} spp={params.spp}"
+    _, cnt = ob.render(desc, q, threads=0)
+    wall = time.perf_counter() - t0
+    return {"value": round(cnt.segments / cnt.seconds / 1e6, 3), "unit": "Msamples/s", "cores": int(cnt.threads_used),
+            "kind": "port", "sample": sample, "seconds": round(cnt.seconds, 3), "wall_seconds": round(wall, 3),
+            "segments": int(cnt.segments), "bytes_per_segment_measured": round(cnt.bytes_per_segment(), 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="cbox", choices=sorted(WORKLOADS))
+    ap.add_argument("--traversal", default="exact", choices=["exact", "pruned"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from pathtracer_cuda_interactive_amd import (PT_BVH_SORT_REFERENCE, PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED,
+                                                 HostScene, _build)
+    from pathtracer_cuda_interactive_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if not os.path.exists(_build.HIP_LIB) or not os.path.exists(_build.HOST_LIB):
+        _build.build_all()
+
+    wl = WORKLOADS[args.scene]
+    hs = HostScene.load(os.path.join(REPO, "tests", "golden", "scenes", args.scene + ".pts"))
+    desc = hs.finalize(PT_BVH_SORT_REFERENCE)           # the reference's own tree (same libstdc++ tie order)
+    spp_total = wl["spp"] * world                        # weak scaling: per-GPU paths constant
+    params = hs.render_params(wl["w"], wl["h"], spp_total)
+    params.traversal = PT_TRAVERSAL_PRUNED if args.traversal == "pruned" else PT_TRAVERSAL_EXACT
+
+    R = D.ShardedRenderer(desc)
+    kernel_ms, resolve_ms, segs, paths = [], [], [], []
+
+    def step(record):
+        frame = R.render(params, rank, world)
+        c = R.scene.counters()                           # syncs this rank's stream; also the HIP-event kernel time
+        if record:
+            kernel_ms.append(c.kernel_ms); resolve_ms.append(c.resolve_ms); segs.append(c.segments); paths.append(c.paths)
+        return frame
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(sum(segs)), float(sum(paths)), float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, total_segs, total_paths, kern = tmax[0].item(), tsum[1].item(), tsum[2].item(), tmax[3].item()
+    else:
+        total_segs, total_paths, kern = t[1].item(), t[2].item(), t[3].item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_segs / elapsed / 1e6
+        # roofline of the dominant kernel (trace_kernel) on rank 0: algorithmic bytes per launch / HIP-event duration
+        seg_launch = float(np.mean(segs))
+        k_ms = float(np.mean(kernel_ms))
+        achieved = wl["bytes_per_segment"] * seg_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.scene}:{args.traversal}")
+        out = {
+            "metric": "Msamples/sec (rays x spp x bounces = intersect() calls per second), " + wl["label"].split(" (")[0],
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: scene fixture tests/golden/scenes/%s.pts (parsed from the reference's scene files), PCG seed 1984" % args.scene,
+            "config": {"workload": wl["label"] + ("" if world == 1 else f"; weak scaling: spp = 64 x {world} GPUs = {spp_total}, rows interleaved over ranks, RCCL gather to rank 0"),
+                       "scene": args.scene, "width": wl["w"], "height": wl["h"], "spp": spp_total, "traversal": args.traversal,
+                       "paths_per_step": int(total_paths / args.steps), "segments_per_step": int(total_segs / args.steps),
+                       "mpaths_per_s": round(total_paths / elapsed / 1e6, 2), "kernel_ms": round(k_ms, 4),
+                       "resolve_ms": round(float(np.mean(resolve_ms)), 4), "lds_scene": int(R.scene.info("lds_scene")),
+                       "grid": int(R.scene.info("grid")), "blocks_per_cu": int(R.scene.info("occupancy")),
+                       "vgprs": int(R.scene.info("vgprs_pruned" if args.traversal == "pruned" else "vgprs")),
+                       "frame_mean": round(float(frame.mean().item()), 6)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "trace_kernel", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
+                         "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
+                                  "see DESIGN.md §Measurement" % R.scene.info("scene_bytes")) if R.scene.info("lds_scene") else
+                                 "working set (%.1f MB) is served by L2/Infinity Cache, see DESIGN.md §Measurement" % (R.scene.info("scene_bytes") / 1e6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, hs.render_params(wl["w"], wl["h"], wl["spp"]), args.scene)
+        print(json.dumps(out), flush=True)
+    R.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
