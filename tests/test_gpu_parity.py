@@ -74,7 +74,7 @@ def test_random_scenes_all_materials(oracle, seed):
     d = hs.finalize()
     p = hs.render_params(56, 40, 6, seed=1000 + seed)
     want, cnt = oracle.render(d, p)
-    assert cnt.term_absorb > 0 and cnt.emit > 0 and cnt.term_rr + cnt.term_miss > 0
+    assert cnt.emit > 0 and cnt.term_rr + cnt.term_miss > 0 and cnt.leaf_tri > 0 and cnt.leaf_sphere > 0
     ds = dev.DeviceScene(d)
     try:
         for trav in TRAVERSALS:

@@ -1,0 +1,69 @@
+"""Condenses a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into tracked files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_pmc.json           per-launch means of every PMC counter for trace_kernel + derived figures
+  profiles/traffic.json             key "<scene>:<traversal>" -> HBM bytes per trace_kernel launch (read by bench.py)
+Usage: python tools/summarize_profile.py <tag> <scene> <traversal>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(tag, scene, traversal):
+    src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(REPO, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
+    kern = {}
+    for r in csv.DictReader(open(ks)):
+        if "trace_kernel" in r["Name"]:
+            kern = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    agg = collections.defaultdict(list)
+    meta = {}
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "trace_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {"grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]), "lds_block_size": int(r["LDS_Block_Size"]),
+                        "vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "scratch": int(r["Scratch_Size"])}
+    c = {k: sum(v) / len(v) for k, v in agg.items()}
+    d = {}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of
+        # wide coalesced reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores (the per-sample float4 stores here).
+        d["hbm_read_bytes"] = 2.0 * c["FETCH_SIZE"] * 1024
+        d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_lane_utilization"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if "GRBM_GUI_ACTIVE" in c and "SQ_INSTS_VALU" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                 # summed over the 8 XCDs
+        d["kernel_cycles"] = cycles
+        d["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles)    # wave64 VALU = 2 cycles on a SIMD-32, 1024 SIMDs
+    if "SQ_WAVE_CYCLES" in c:
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in c:
+                d[k.lower() + "_share_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+    if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
+        d["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    out = {"tag": tag, "scene": scene, "traversal": traversal, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline",
+           "kernel_trace": kern, "dispatch": meta, "counters_mean_per_launch": c, "derived": d}
+    json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+    tpath = os.path.join(dst, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    if "hbm_bytes_per_launch" in d:
+        traffic[f"{scene}:{traversal}"] = round(d["hbm_bytes_per_launch"])
+        json.dump(traffic, open(tpath, "w"), indent=1)
+    print(json.dumps({"kernel": kern, "derived": d}, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
