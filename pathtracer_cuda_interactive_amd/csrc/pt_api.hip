@@ -167,6 +167,153 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
     }
 }
 
+// trace_kernel_v2 — same work, different schedule: traversal is decoupled from shading.
+// Every lane runs a small state machine {traversing | waiting for the scheduler phase}.  The wave keeps
+// executing traversal steps (INNER inner-node visits + at most one leaf test per iteration) for the lanes that
+// still traverse; lanes whose traversal finished wait until at least THRESH lanes can make progress in the
+// scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
+// (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
+// the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
+template <bool LDS_SCENE, bool PRUNE, bool STATS, int THRESH, int INNER>
+__global__ __launch_bounds__(kBlock) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
+                                                          float4* __restrict__ samples,
+                                                          uint32_t* __restrict__ work_counter,
+                                                          unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ptd::SceneView sv;
+    if (LDS_SCENE) {
+        stage_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes * sizeof(DNode));
+        stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
+        stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
+        stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
+        stage_to_lds(smem + lp.emis_off, scn.emission, (uint32_t)scn.num_emission * sizeof(DEmission));
+        __syncthreads();
+        sv.nodes = reinterpret_cast<const DNode*>(smem + lp.nodes_off);
+        sv.prims = reinterpret_cast<const DPrim*>(smem + lp.prims_off);
+        sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
+        sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
+        sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
+    } else {
+        sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
+        sv.materials = scn.materials; sv.emission = scn.emission;
+    }
+    sv.num_emission = scn.num_emission;
+    sv.root_ref = scn.root_ref;
+    sv.bg = ptm::mk(scn.bg[0], scn.bg[1], scn.bg[2]);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
+
+    uint32_t chunk_cur = 0, chunk_end = 0;
+    bool exhausted = false;
+    bool alive = false;
+    ptd::Ray ray;
+    ray.org = ptm::mk(0, 0, 0); ray.dir = ptm::mk(0, 0, 1); ray.tnear = 0; ray.tfar = 0;
+    ptd::Trav tv;
+    tv.inv = ptm::mk(1, 1, 1);
+    tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
+    tv.cur = kDone; tv.sp = 0;
+    ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
+    ptm::Pcg rng;
+    rng.state = 0; rng.inc = 1;
+    int depth = 0;
+    uint32_t my_w = 0;
+    uint32_t n_paths = 0, n_segs = 0;
+    ptd::TravStats st;
+    st.nodes = 0; st.leaves = 0;
+
+    for (;;) {
+        const bool idle = tv.cur == kDone;
+        const unsigned long long idle_mask = __ballot(idle);
+        const bool work_left = !(exhausted && chunk_cur >= chunk_end);        // wave-uniform
+        const int n_pend = __popcll(__ballot(idle && (alive || work_left)));
+        if (n_pend >= THRESH || idle_mask == ~0ull) {
+            if (n_pend == 0) break;          // every lane idle, no live path, no work left
+            // (1) finish the segments whose traversal completed (radiance.cuh:26-75)
+            if (idle && alive) {
+                bool cont = false;
+                if (tv.best.prim < 0) {
+                    L = L + T * sv.bg;
+                } else {
+                    const ptd::Surface sf = ptd::make_surface(sv, ray, tv.best);
+                    cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                    depth++;
+                    if (depth >= rp.max_depth) cont = false;
+                }
+                if (!cont) {
+                    samples[my_w] = make_float4(L.x, L.y, L.z, 0.0f);
+                    alive = false;
+                }
+            }
+            // (2) refill dead lanes (main.cu:32-44)
+            const unsigned long long need = __ballot(idle && !alive);
+            if (need) {
+                if (chunk_cur >= chunk_end && !exhausted) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(work_counter, kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= rp.total_work) exhausted = true;
+                    else { chunk_cur = base; chunk_end = min(base + kChunk, rp.total_work); }
+                }
+                const uint32_t avail = chunk_end - chunk_cur;
+                if (avail) {
+                    const uint32_t rank = lane_rank(need);
+                    const uint32_t n = (uint32_t)__popcll(need);
+                    if (idle && !alive && rank < avail) {
+                        const uint32_t w = chunk_cur + rank;
+                        const uint32_t s_local = w / rp.npix;
+                        const uint32_t pix = w - s_local * rp.npix;
+                        const uint32_t r = pix / (uint32_t)rp.width;
+                        const int i = (int)(pix - r * (uint32_t)rp.width);
+                        const int j = rp.row_begin + (int)r * rp.row_step;
+                        const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;
+                        const uint64_t stream = pixel_index * (uint64_t)rp.stream_stride +
+                                                (uint64_t)(rp.sample_base + (int)s_local);
+                        rng = ptm::pcg_init(stream, rp.seed);
+                        const float ru = ptm::pcg_float(rng);
+                        const float u = ((float)i + ru) / (float)rp.width;
+                        const float rv = ptm::pcg_float(rng);
+                        const float v = ((float)j + rv) / (float)rp.height;
+                        ray = ptd::primary_ray(rp, u, v);
+                        L = ptm::mk(0, 0, 0);
+                        T = ptm::mk(1, 1, 1);
+                        depth = 0;
+                        my_w = w;
+                        alive = true;
+                        n_paths++;
+                    }
+                    chunk_cur += min(n, avail);
+                }
+            }
+            // (3) start the next traversal (scene.h:247-256)
+            if (idle && alive) {
+                ptd::trav_begin(sv, ray, tv);
+                n_segs++;
+            }
+        }
+        // ---- traversal burst
+#pragma unroll
+        for (int k = 0; k < INNER; k++) {
+            if (tv.cur >= 0) {
+                if (STATS) st.nodes++;
+                ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+            }
+        }
+        if (tv.cur < 0 && tv.cur != kDone) {
+            if (STATS) st.leaves++;
+            ptd::leaf_step(sv, ray, tv, stk);
+        }
+    }
+    unsigned long long a = wave_sum(n_paths), b = wave_sum(n_segs);
+    unsigned long long c = STATS ? wave_sum(st.nodes) : 0ull, d = STATS ? wave_sum(st.leaves) : 0ull;
+    if (lane == 0) {
+        atomicAdd(&counters[0], a);
+        atomicAdd(&counters[1], b);
+        if (STATS) { atomicAdd(&counters[2], c); atomicAdd(&counters[3], d); }
+    }
+}
+
 // mode 0: fb = (prev + sum) * scale   (prev = accum if !first)        [final pass of pt_render]
 // mode 1: accum = prev + sum          (prev = accum if !first else 0) [intermediate pass]
 // mode 2: accum = first ? sum : accum + sum, sum started from zero    [render_progressive, main.cu:72-86]
@@ -307,6 +454,8 @@ struct pt_scene {
     int64_t opt_scratch_bytes = 0;
     int64_t opt_force_global = 0;
     int64_t opt_stats = 0;
+    int64_t opt_kernel = 1;          // 1 = segment-synchronous wavefront kernel, 2 = decoupled traversal/shading
+    int64_t opt_v2_thresh = 32, opt_v2_inner = 2;
     // info of last launch
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
@@ -492,13 +641,40 @@ LdsPlan make_plan(const pt_scene* S, bool lds_scene) {
 
 using TraceFn = void (*)(SceneDev, RenderDev, LdsPlan, float4*, uint32_t*, unsigned long long*);
 
-TraceFn pick_kernel(bool lds, bool prune, bool stats) {
+TraceFn pick_kernel_v1(bool lds, bool prune, bool stats) {
     if (lds) {
         if (prune) return stats ? trace_kernel<true, true, true> : trace_kernel<true, true, false>;
         return stats ? trace_kernel<true, false, true> : trace_kernel<true, false, false>;
     }
     if (prune) return stats ? trace_kernel<false, true, true> : trace_kernel<false, true, false>;
     return stats ? trace_kernel<false, false, true> : trace_kernel<false, false, false>;
+}
+
+template <int THRESH, int INNER>
+TraceFn pick_v2_ti(bool lds, bool prune, bool stats) {
+    if (lds) {
+        if (prune) return stats ? trace_kernel_v2<true, true, true, THRESH, INNER> : trace_kernel_v2<true, true, false, THRESH, INNER>;
+        return stats ? trace_kernel_v2<true, false, true, THRESH, INNER> : trace_kernel_v2<true, false, false, THRESH, INNER>;
+    }
+    if (prune) return stats ? trace_kernel_v2<false, true, true, THRESH, INNER> : trace_kernel_v2<false, true, false, THRESH, INNER>;
+    return stats ? trace_kernel_v2<false, false, true, THRESH, INNER> : trace_kernel_v2<false, false, false, THRESH, INNER>;
+}
+
+// (thresh, inner) variants compiled in; see DESIGN.md §4 for the measured choice.
+TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner) {
+#define PT_V2(T, I) if (thresh == T && inner == I) return pick_v2_ti<T, I>(lds, prune, stats);
+    PT_V2(16, 1) PT_V2(16, 2) PT_V2(16, 4)
+    PT_V2(32, 1) PT_V2(32, 2) PT_V2(32, 4)
+    PT_V2(48, 1) PT_V2(48, 2) PT_V2(48, 4)
+#undef PT_V2
+    return nullptr;
+}
+
+TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats);
+
+TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats) {
+    if (S->opt_kernel == 2) return pick_kernel_v2(lds, prune, stats, (int)S->opt_v2_thresh, (int)S->opt_v2_inner);
+    return pick_kernel_v1(lds, prune, stats);
 }
 
 struct RowSel {
@@ -551,7 +727,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     const bool lds_scene = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;
     const LdsPlan lp = make_plan(S, lds_scene);
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
-    TraceFn fn = pick_kernel(lds_scene, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
+    TraceFn fn = pick_kernel(S, lds_scene, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
+    if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
     if (lp.total > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
     int occ = 0;
@@ -721,6 +898,9 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "scratch_bytes") S->opt_scratch_bytes = value;
     else if (k == "force_global") S->opt_force_global = value;
     else if (k == "stats") S->opt_stats = value;
+    else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
+    else if (k == "v2_thresh") S->opt_v2_thresh = value;
+    else if (k == "v2_inner") S->opt_v2_inner = value;
     else return fail(PT_ERR_INVALID_ARG, "unknown option " + k);
     return PT_OK;
 }
@@ -741,7 +921,9 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
         const bool lds = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pick_kernel(lds, k == "vgprs_pruned", S->opt_stats != 0))));
+        TraceFn fn = pick_kernel(S, lds, k == "vgprs_pruned", S->opt_stats != 0);
+        if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
         *value = fa.numRegs;
     } else return fail(PT_ERR_INVALID_ARG, "unknown info key " + k);
     return PT_OK;

@@ -52,129 +52,151 @@ struct SceneView {
 
 __device__ __forceinline__ float4 ld4(const void* p, int i) { return reinterpret_cast<const float4*>(p)[i]; }
 
-// Closest hit.  PRUNE=false visits exactly the nodes the reference visits.
-// PRUNE=true additionally skips a child whose box entry distance is beyond the current
-// closest hit; the set of candidate hits that can win is unchanged.
+// Per-lane traversal state.  It lives in registers across scheduler phases of trace_kernel_v2
+// (a lane keeps traversing while other lanes of its wave shade or start new paths).
+struct Trav {
+    V3 inv;            // 1/dir, hoisted out of Hit() (bbox.cuh:36) — same bits
+    Hit best;          // closest hit so far (scene.h:248-249,270-273)
+    int32_t cur;       // node reference being visited; kDone = traversal finished
+    int32_t sp;        // entries on this lane's LDS stack column
+};
+
+__device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, Trav& t) {
+    t.inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+    t.best.t = FLT_MAX; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = -1;
+    t.cur = sv.root_ref;           // scene.h:256: the root is pushed without a box test
+    t.sp = 0;
+}
+
+// One inner-node visit (requires t.cur >= 0): test both child boxes, descend into the nearer one,
+// push the farther one (scene.h:278-297).  PRUNE=false visits exactly the nodes the reference visits;
+// PRUNE=true also skips a child whose box entry lies beyond the closest hit.
+template <bool PRUNE>
+__device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, int32_t* stk) {
+    const DNode* nd = sv.nodes + t.cur;
+    const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x
+    const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy
+    const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz
+    const float4 d = ld4(nd, 3);    // left right - -
+    const V3 inv = t.inv;
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    // bbox.cuh:36-55 for the left box
+    float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
+    float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
+    float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
+    float ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
+    float ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
+    bool hl = ltf >= fmax2(0.0f, ltn);
+    // right box
+    float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
+    float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
+    float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
+    float rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
+    float rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
+    bool hr = rtf >= fmax2(0.0f, rtn);
+    if (PRUNE) {
+        hl = hl && !(ltn > t.best.t);
+        hr = hr && !(rtn > t.best.t);
+    }
+    const int32_t L = __builtin_bit_cast(int32_t, d.x);
+    const int32_t R = __builtin_bit_cast(int32_t, d.y);
+    if (hl && hr) {
+        // scene.h:281-289: visit the nearer box first; on a tie the right one
+        const bool left_first = ltn < rtn;
+        stk[t.sp * 64] = left_first ? R : L;
+        t.sp++;
+        t.cur = left_first ? L : R;
+    } else if (hl) {
+        t.cur = L;
+    } else if (hr) {
+        t.cur = R;
+    } else if (t.sp > 0) {
+        t.sp--;
+        t.cur = stk[t.sp * 64];
+    } else {
+        t.cur = kDone;
+    }
+}
+
+// One leaf visit (requires t.cur < 0 && t.cur != kDone): primitive test, keep the hit if strictly closer, pop.
+__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, int32_t* stk) {
+    const int32_t prim = ~t.cur;
+    const DPrim* pr = sv.prims + prim;
+    const float4 a = ld4(pr, 0);
+    const float4 b = ld4(pr, 1);
+    const float4 c = ld4(pr, 2);
+    const V3 o = ray.org;
+    const int32_t info = __builtin_bit_cast(int32_t, c.y);
+    if (info >= 0) {
+        // Möller–Trumbore, shape.cuh:188-215
+        const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
+        const V3 e1 = p1 - p0;
+        const V3 e2 = p2 - p0;
+        const V3 s1 = cross(ray.dir, e2);
+        const float divisor = dot(s1, e1);
+        if (divisor != 0.0f) {
+            const float inv_divisor = 1.0f / divisor;
+            const V3 s = o - p0;
+            const float u = dot(s, s1) * inv_divisor;
+            const V3 s2 = cross(s, e1);
+            const float v = dot(ray.dir, s2) * inv_divisor;
+            const float tt = dot(e2, s2) * inv_divisor;
+            if (tt > ray.tnear && tt < ray.tfar && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && tt < t.best.t) {
+                t.best.t = tt; t.best.u = u; t.best.v = v; t.best.prim = prim;
+            }
+        }
+    } else {
+        // sphere, shape.cuh:135-186
+        const V3 center = mk(a.x, a.y, a.z);
+        const float radius = a.w;
+        const V3 vv = o - center;
+        const float A = dot(ray.dir, ray.dir);
+        const float B = 2.0f * dot(ray.dir, vv);
+        const float C = dot(vv, vv) - radius * radius;
+        float t0 = 0.0f, t1 = 0.0f;
+        bool ok = true;
+        if (A == 0.0f) {
+            if (B == 0.0f) ok = false;
+            else { t0 = -C / B; t1 = t0; }
+        } else {
+            const float disc = B * B - 4.0f * A * C;
+            if (disc < 0.0f) ok = false;
+            else {
+                const float rd = __builtin_sqrtf(disc);
+                if (B >= 0.0f) { t0 = (-B - rd) / (2.0f * A); t1 = 2.0f * C / (-B - rd); }
+                else { t0 = 2.0f * C / (-B + rd); t1 = (-B + rd) / (2.0f * A); }
+            }
+        }
+        if (ok) {
+            if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+            float tt = t0;
+            if (t1 >= ray.tnear && t1 < ray.tfar && tt < ray.tnear) tt = t1;
+            if (tt >= ray.tnear && tt < ray.tfar && tt < t.best.t) {
+                t.best.t = tt; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = prim;
+            }
+        }
+    }
+    if (t.sp > 0) { t.sp--; t.cur = stk[t.sp * 64]; }
+    else t.cur = kDone;
+}
+
+// Closest hit of one ray, run to completion (while-while loop): intersect() of scene.h:246-301.
 // `stk` points at this lane's column of the wave's LDS stack (entry k at stk[k*64]).
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, int32_t* stk, TravStats& st) {
-    const V3 inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
-    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    const V3 o = ray.org;
-    Hit best;
-    best.t = FLT_MAX; best.u = 0.0f; best.v = 0.0f; best.prim = -1;
-    int32_t cur = sv.root_ref;
-    int sp = 0;
-
-    while (cur != kDone) {
-        // ---- descend through inner nodes until this lane holds a leaf (or is done)
-        while (cur >= 0) {
-            const DNode* nd = sv.nodes + cur;
-            const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x
-            const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy
-            const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz
-            const float4 d = ld4(nd, 3);    // left right - -
+    Trav t;
+    trav_begin(sv, ray, t);
+    while (t.cur != kDone) {
+        while (t.cur >= 0) {                    // descend through inner nodes until this lane holds a leaf
             if (STATS) st.nodes++;
-            // bbox.cuh:36-55 for the left box
-            float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
-            float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
-            float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
-            float ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
-            float ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
-            bool hl = ltf >= fmax2(0.0f, ltn);
-            // right box
-            float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
-            float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
-            float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
-            float rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
-            float rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
-            bool hr = rtf >= fmax2(0.0f, rtn);
-            if (PRUNE) {
-                hl = hl && !(ltn > best.t);
-                hr = hr && !(rtn > best.t);
-            }
-            const int32_t L = __builtin_bit_cast(int32_t, d.x);
-            const int32_t R = __builtin_bit_cast(int32_t, d.y);
-            if (hl && hr) {
-                // scene.h:281-289: visit the nearer box first; on a tie the right one
-                const bool left_first = ltn < rtn;
-                stk[sp * 64] = left_first ? R : L;
-                sp++;
-                cur = left_first ? L : R;
-            } else if (hl) {
-                cur = L;
-            } else if (hr) {
-                cur = R;
-            } else if (sp > 0) {
-                sp--;
-                cur = stk[sp * 64];
-            } else {
-                cur = kDone;
-            }
+            inner_step<PRUNE>(sv, ray.org, t, stk);
         }
-        // ---- leaf: one primitive test, then pop
-        if (cur != kDone) {
-            const int32_t prim = ~cur;
-            const DPrim* pr = sv.prims + prim;
-            const float4 a = ld4(pr, 0);
-            const float4 b = ld4(pr, 1);
-            const float4 c = ld4(pr, 2);
+        if (t.cur != kDone) {                   // one primitive test, then pop
             if (STATS) st.leaves++;
-            const int32_t info = __builtin_bit_cast(int32_t, c.y);
-            if (info >= 0) {
-                // Möller–Trumbore, shape.cuh:188-215
-                const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
-                const V3 e1 = p1 - p0;
-                const V3 e2 = p2 - p0;
-                const V3 s1 = cross(ray.dir, e2);
-                const float divisor = dot(s1, e1);
-                if (divisor != 0.0f) {
-                    const float inv_divisor = 1.0f / divisor;
-                    const V3 s = o - p0;
-                    const float u = dot(s, s1) * inv_divisor;
-                    const V3 s2 = cross(s, e1);
-                    const float v = dot(ray.dir, s2) * inv_divisor;
-                    const float t = dot(e2, s2) * inv_divisor;
-                    if (t > ray.tnear && t < ray.tfar && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t < best.t) {
-                        best.t = t; best.u = u; best.v = v; best.prim = prim;
-                    }
-                }
-            } else {
-                // sphere, shape.cuh:135-186
-                const V3 center = mk(a.x, a.y, a.z);
-                const float radius = a.w;
-                const V3 vv = o - center;
-                const float A = dot(ray.dir, ray.dir);
-                const float B = 2.0f * dot(ray.dir, vv);
-                const float C = dot(vv, vv) - radius * radius;
-                float t0 = 0.0f, t1 = 0.0f;
-                bool ok = true;
-                if (A == 0.0f) {
-                    if (B == 0.0f) ok = false;
-                    else { t0 = -C / B; t1 = t0; }
-                } else {
-                    const float disc = B * B - 4.0f * A * C;
-                    if (disc < 0.0f) ok = false;
-                    else {
-                        const float rd = __builtin_sqrtf(disc);
-                        if (B >= 0.0f) { t0 = (-B - rd) / (2.0f * A); t1 = 2.0f * C / (-B - rd); }
-                        else { t0 = 2.0f * C / (-B + rd); t1 = (-B + rd) / (2.0f * A); }
-                    }
-                }
-                if (ok) {
-                    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
-                    float t = t0;
-                    if (t1 >= ray.tnear && t1 < ray.tfar && t < ray.tnear) t = t1;
-                    if (t >= ray.tnear && t < ray.tfar && t < best.t) {
-                        best.t = t; best.u = 0.0f; best.v = 0.0f; best.prim = prim;
-                    }
-                }
-            }
-            if (sp > 0) { sp--; cur = stk[sp * 64]; }
-            else cur = kDone;
+            leaf_step(sv, ray, t, stk);
         }
     }
-    return best;
+    return t.best;
 }
 
 // Surface record of the closest hit (scene.h:186-217 / shape.cuh:168-180).
