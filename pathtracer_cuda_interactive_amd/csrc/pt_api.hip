@@ -174,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 // scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
 // (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
 // the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
-template <bool LDS_SCENE, bool PRUNE, bool STATS, int THRESH, int INNER>
-__global__ __launch_bounds__(kBlock) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
+template <bool LDS_SCENE, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
                                                           uint32_t* __restrict__ work_counter,
                                                           unsigned long long* __restrict__ counters) {
@@ -293,11 +293,18 @@ __global__ __launch_bounds__(kBlock) void trace_kernel_v2(SceneDev scn, RenderDe
             }
         }
         // ---- traversal burst
-#pragma unroll
-        for (int k = 0; k < INNER; k++) {
-            if (tv.cur >= 0) {
+        if (INNER == 0) {
+            while (tv.cur >= 0) {
                 if (STATS) st.nodes++;
                 ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < (INNER > 0 ? INNER : 1); k++) {
+                if (tv.cur >= 0) {
+                    if (STATS) st.nodes++;
+                    ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+                }
             }
         }
         if (tv.cur < 0 && tv.cur != kDone) {
@@ -454,8 +461,8 @@ struct pt_scene {
     int64_t opt_scratch_bytes = 0;
     int64_t opt_force_global = 0;
     int64_t opt_stats = 0;
-    int64_t opt_kernel = 1;          // 1 = segment-synchronous wavefront kernel, 2 = decoupled traversal/shading
-    int64_t opt_v2_thresh = 32, opt_v2_inner = 2;
+    int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
+    int64_t opt_v2_thresh = 40, opt_v2_inner = 4, opt_v2_minw = 6;
     // info of last launch
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
@@ -650,22 +657,22 @@ TraceFn pick_kernel_v1(bool lds, bool prune, bool stats) {
     return stats ? trace_kernel<false, false, true> : trace_kernel<false, false, false>;
 }
 
-template <int THRESH, int INNER>
+template <int THRESH, int INNER, int MINW>
 TraceFn pick_v2_ti(bool lds, bool prune, bool stats) {
     if (lds) {
-        if (prune) return stats ? trace_kernel_v2<true, true, true, THRESH, INNER> : trace_kernel_v2<true, true, false, THRESH, INNER>;
-        return stats ? trace_kernel_v2<true, false, true, THRESH, INNER> : trace_kernel_v2<true, false, false, THRESH, INNER>;
+        if (prune) return stats ? trace_kernel_v2<true, true, true, THRESH, INNER, MINW> : trace_kernel_v2<true, true, false, THRESH, INNER, MINW>;
+        return stats ? trace_kernel_v2<true, false, true, THRESH, INNER, MINW> : trace_kernel_v2<true, false, false, THRESH, INNER, MINW>;
     }
-    if (prune) return stats ? trace_kernel_v2<false, true, true, THRESH, INNER> : trace_kernel_v2<false, true, false, THRESH, INNER>;
-    return stats ? trace_kernel_v2<false, false, true, THRESH, INNER> : trace_kernel_v2<false, false, false, THRESH, INNER>;
+    if (prune) return stats ? trace_kernel_v2<false, true, true, THRESH, INNER, MINW> : trace_kernel_v2<false, true, false, THRESH, INNER, MINW>;
+    return stats ? trace_kernel_v2<false, false, true, THRESH, INNER, MINW> : trace_kernel_v2<false, false, false, THRESH, INNER, MINW>;
 }
 
-// (thresh, inner) variants compiled in; see DESIGN.md §4 for the measured choice.
-TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner) {
-#define PT_V2(T, I) if (thresh == T && inner == I) return pick_v2_ti<T, I>(lds, prune, stats);
-    PT_V2(16, 1) PT_V2(16, 2) PT_V2(16, 4)
-    PT_V2(32, 1) PT_V2(32, 2) PT_V2(32, 4)
-    PT_V2(48, 1) PT_V2(48, 2) PT_V2(48, 4)
+// (thresh, inner, min-waves-per-SIMD) variants compiled in.  Measured on MI355X (tools/gpu_tune.py, round 1):
+// T40/I4/W6 is the fastest on cbox (4.90 ms) and bunny (11.8 ms); I8 and unbounded descent are slower, T56 starves
+// the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %.
+TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner, int minw) {
+#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(lds, prune, stats);
+    PT_V2(40, 4, 6) PT_V2(32, 4, 6) PT_V2(48, 4, 6) PT_V2(40, 4, 1)
 #undef PT_V2
     return nullptr;
 }
@@ -673,7 +680,7 @@ TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner) 
 TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats);
 
 TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats) {
-    if (S->opt_kernel == 2) return pick_kernel_v2(lds, prune, stats, (int)S->opt_v2_thresh, (int)S->opt_v2_inner);
+    if (S->opt_kernel == 2) return pick_kernel_v2(lds, prune, stats, (int)S->opt_v2_thresh, (int)S->opt_v2_inner, (int)S->opt_v2_minw);
     return pick_kernel_v1(lds, prune, stats);
 }
 
@@ -901,6 +908,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
     else if (k == "v2_inner") S->opt_v2_inner = value;
+    else if (k == "v2_minw") S->opt_v2_minw = value;
     else return fail(PT_ERR_INVALID_ARG, "unknown option " + k);
     return PT_OK;
 }

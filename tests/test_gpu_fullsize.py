@@ -46,6 +46,10 @@ def test_fullsize_config_properties(oracle, name):
             q.row_begin, q.row_end, q.row_stride = r, h, 8
             out[r::8] = ds.render(q)
         assert_bit_equal(out, exact, name + " shards")
+        # (3b) the segment-synchronous kernel (v1) computes the same frame as the decoupled scheduler (v2, default)
+        ds.set_option("kernel", 1)
+        assert_bit_equal(ds.render(p, traversal=PT_TRAVERSAL_EXACT), exact, name + " kernel v1")
+        ds.set_option("kernel", 2)
         # (4) scene staged in LDS vs read from global memory
         ds.set_option("force_global", 1)
         assert_bit_equal(ds.render(p), exact, name + " global")

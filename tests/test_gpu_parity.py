@@ -37,16 +37,46 @@ def dscenes():
 @pytest.mark.parametrize("path", IMAGES, ids=os.path.basename)
 @pytest.mark.parametrize("trav", TRAVERSALS)
 @pytest.mark.parametrize("force_global", [0, 1])
-def test_device_reproduces_golden_image(dscenes, path, trav, force_global):
+@pytest.mark.parametrize("kernel", [2, 1])
+def test_device_reproduces_golden_image(dscenes, path, trav, force_global, kernel):
+    """kernel 2 = decoupled traversal/shading scheduler (default), kernel 1 = segment-synchronous wavefront loop."""
     name, w, h, spp = parse_image_name(path)
     hs, _ = load_scene(name)
     ds = dscenes(name)
     ds.set_option("force_global", force_global)
-    img = ds.render(hs.render_params(w, h, spp), traversal=trav)
-    ds.set_option("force_global", 0)
+    ds.set_option("kernel", kernel)
+    try:
+        img = ds.render(hs.render_params(w, h, spp), traversal=trav)
+    finally:
+        ds.set_option("force_global", 0)
+        ds.set_option("kernel", 2)
     want = np.load(path)
     assert np.abs(img - want).max() <= TOL
-    assert_bit_equal(img, want, f"{name} trav={trav} global={force_global}")
+    assert_bit_equal(img, want, f"{name} trav={trav} global={force_global} kernel={kernel}")
+
+
+@pytest.mark.parametrize("thresh,inner,minw", [(40, 4, 6), (32, 4, 6), (48, 4, 6), (40, 4, 1)])
+def test_scheduler_variants_are_bit_identical(oracle, dscenes, thresh, inner, minw):
+    """The scheduling knobs of trace_kernel_v2 change WHEN a lane runs, never what it computes."""
+    hs, d = load_scene("cbox")
+    ds = dscenes("cbox")
+    p = hs.render_params(72, 54, 7, seed=3)
+    want, cnt = oracle.render(d, p)
+    for k, v in (("v2_thresh", thresh), ("v2_inner", inner), ("v2_minw", minw), ("stats", 1)):
+        ds.set_option(k, v)
+    try:
+        img = ds.render(p)
+        c = ds.counters()
+    finally:
+        for k, v in (("v2_thresh", 40), ("v2_inner", 4), ("v2_minw", 6), ("stats", 0)):
+            ds.set_option(k, v)
+    assert_bit_equal(img, want, f"T{thresh} I{inner} W{minw}")
+    assert (c.paths, c.segments, c.node_visits) == (cnt.paths, cnt.segments, cnt.inner_pops)
+    ds.set_option("v2_thresh", 17)
+    with pytest.raises(PtError) as e:            # not compiled in
+        ds.render(p)
+    ds.set_option("v2_thresh", 40)
+    assert e.value.status == PT_ERR_INVALID_ARG
 
 
 @pytest.mark.parametrize("name,w,h,spp", [("cbox", 96, 72, 9), ("scene1", 80, 60, 12), ("scene1_phong", 64, 64, 10),
