@@ -34,18 +34,6 @@ WORKLOADS = {
 }
 
 
-def usable_cores():
-    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
-
-
 def cpu_baseline(desc, params, name):
     """The oracle (CPU port of the same algorithm) timed on this box's host cores — reported, never shipped."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -59,7 +47,7 @@ def cpu_baseline(desc, params, name):
     else:
         q = params
         sample = f"full frame {params.width}x{params.height} spp={params.spp}"
-    _, cnt = ob.render(desc, q, threads=usable_cores())
+    _, cnt = ob.render(desc, q, threads=ob.usable_cores())
     wall = time.perf_counter() - t0
     return {"value": round(cnt.segments / cnt.seconds / 1e6, 3), "unit": "Msamples/s", "cores": int(cnt.threads_used),
             "kind": "port", "sample": sample, "seconds": round(cnt.seconds, 3), "wall_seconds": round(wall, 3),

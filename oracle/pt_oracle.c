@@ -8,6 +8,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
@@ -134,7 +135,13 @@ static double now_s(void) {
 
 static int run_job(job_t* J, pt_oracle_counters* counters) {
     int nt = J->opts.threads;
-    if (nt <= 0) nt = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    if (nt <= 0) {
+        /* default: the CPUs this process may run on, capped (GPU boxes expose 256 hardware threads behind a
+         * 16-CPU quota and a task-count guard; oversubscribing buys nothing) */
+        cpu_set_t set;
+        nt = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)sysconf(_SC_NPROCESSORS_ONLN);
+        if (nt > 32) nt = 32;
+    }
     if (nt < 1) nt = 1;
     if (nt > 256) nt = 256;
     pthread_t* th = (pthread_t*)calloc((size_t)nt, sizeof(pthread_t));
@@ -146,8 +153,17 @@ static int run_job(job_t* J, pt_oracle_counters* counters) {
         ta[0].job = J; ta[0].tid = 0;
         worker(&ta[0]);
     } else {
-        for (int t = 0; t < nt; t++) { ta[t].job = J; ta[t].tid = t; pthread_create(&th[t], NULL, worker, &ta[t]); }
-        for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+        int started = 0;
+        for (int t = 0; t < nt; t++) {
+            ta[t].job = J; ta[t].tid = t;
+            if (pthread_create(&th[t], NULL, worker, &ta[t]) != 0) break;   /* task limit hit: go on with fewer threads */
+            started++;
+        }
+        if (started < nt) {                    /* the work list is shared: the calling thread drains what is left */
+            ta[started].job = J; ta[started].tid = started;
+            worker(&ta[started]);
+        }
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
     }
     double t1 = now_s();
     if (counters) {

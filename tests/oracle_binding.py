@@ -39,6 +39,18 @@ class OracleCounters(C.Structure):
 _lib = None
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
     return ORACLE_LIB
@@ -73,7 +85,7 @@ def _fp(a):
 
 def render(desc, params, math_mode=MATH_DET, rng_mode=RNG_PER_SAMPLE, threads=0, accumulate=False):
     """Returns (image[rows,W,3] float32, OracleCounters)."""
-    opts = OracleOpts(math_mode, rng_mode, threads, 1 if accumulate else 0)
+    opts = OracleOpts(math_mode, rng_mode, threads if threads > 0 else usable_cores(), 1 if accumulate else 0)
     img = np.zeros((params.num_rows(), params.width, 3), dtype=np.float32)
     cnt = OracleCounters()
     _chk(lib().pt_oracle_render(C.byref(desc), C.byref(params), C.byref(opts), _fp(img), C.byref(cnt)), "oracle render")
@@ -83,7 +95,7 @@ def render(desc, params, math_mode=MATH_DET, rng_mode=RNG_PER_SAMPLE, threads=0,
 def render_pixels(desc, params, xy, math_mode=MATH_DET, rng_mode=RNG_PER_SAMPLE, threads=0):
     xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
     out = np.zeros((xy.shape[0], 3), dtype=np.float32)
-    opts = OracleOpts(math_mode, rng_mode, threads, 0)
+    opts = OracleOpts(math_mode, rng_mode, threads if threads > 0 else usable_cores(), 0)
     cnt = OracleCounters()
     _chk(lib().pt_oracle_render_pixels(C.byref(desc), C.byref(params), C.byref(opts),
                                        xy.ctypes.data_as(C.POINTER(C.c_int32)), xy.shape[0], _fp(out), C.byref(cnt)),
