@@ -156,7 +156,7 @@ def main():
                        "frame_mean": round(float(frame.mean().item()), 6)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "trace_kernel", "kernel_ms": round(k_ms, 4),
+                         "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
                          "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
                                   "see DESIGN.md §Measurement" % R.scene.info("scene_bytes")) if R.scene.info("lds_scene") else

@@ -47,6 +47,16 @@ __device__ __forceinline__ void stage_to_lds(void* dst, const void* src, uint32_
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
 }
 
+// Node placement in LDS.  An 80-B stride (16 bank positions instead of 4 for ds_read_b128) was measured on cbox:
+// no gain within run-to-run noise (5.02 vs 4.90 ms, tools/gpu_tune.py round 3) although 41 % of LDS cycles are
+// bank conflicts — the kernel is VALU-issue bound, not LDS bound — so nodes stay densely packed.
+constexpr uint32_t kLdsNodeStride = 64;
+__device__ __forceinline__ void stage_nodes_to_lds(void* dst, const DNode* src, uint32_t n) {
+    const float4* s = reinterpret_cast<const float4*>(src);
+    for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x)
+        *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(dst) + (i >> 2) * kLdsNodeStride + (i & 3) * 16) = s[i];
+}
+
 template <bool LDS_SCENE, bool PRUNE, bool STATS>
 __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                        float4* __restrict__ samples,
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ptd::SceneView sv;
     if (LDS_SCENE) {
-        stage_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes * sizeof(DNode));
+        stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
         stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
         stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
         stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
@@ -66,9 +76,11 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
         sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
         sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
         sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
+        sv.node_stride = kLdsNodeStride;
     } else {
         sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
         sv.materials = scn.materials; sv.emission = scn.emission;
+        sv.node_stride = sizeof(DNode);
     }
     sv.num_emission = scn.num_emission;
     sv.root_ref = scn.root_ref;
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ptd::SceneView sv;
     if (LDS_SCENE) {
-        stage_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes * sizeof(DNode));
+        stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
         stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
         stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
         stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
@@ -193,9 +205,11 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
         sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
         sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
         sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
+        sv.node_stride = kLdsNodeStride;
     } else {
         sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
         sv.materials = scn.materials; sv.emission = scn.emission;
+        sv.node_stride = sizeof(DNode);
     }
     sv.num_emission = scn.num_emission;
     sv.root_ref = scn.root_ref;
@@ -355,6 +369,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     ptd::SceneView sv;
     sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
     sv.materials = scn.materials; sv.emission = scn.emission;
+    sv.node_stride = sizeof(DNode);
     sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
     sv.bg = ptm::mk(0, 0, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -428,7 +443,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-constexpr uint32_t kLdsSceneLimit = 40 * 1024;   // scenes up to this size are staged whole into LDS
+constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
 
 uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
@@ -634,7 +649,7 @@ LdsPlan make_plan(const pt_scene* S, bool lds_scene) {
     LdsPlan lp{};
     uint32_t off = 0;
     if (lds_scene) {
-        lp.nodes_off = off; off = align16(off + (uint32_t)S->dev.num_nodes * sizeof(DNode));
+        lp.nodes_off = off; off = align16(off + (uint32_t)S->dev.num_nodes * kLdsNodeStride);
         lp.prims_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DPrim));
         lp.normals_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DNormals));
         lp.mats_off = off; off = align16(off + (uint32_t)S->dev.num_materials * sizeof(DMaterial));
@@ -669,7 +684,8 @@ TraceFn pick_v2_ti(bool lds, bool prune, bool stats) {
 
 // (thresh, inner, min-waves-per-SIMD) variants compiled in.  Measured on MI355X (tools/gpu_tune.py, round 1):
 // T40/I4/W6 is the fastest on cbox (4.90 ms) and bunny (11.8 ms); I8 and unbounded descent are slower, T56 starves
-// the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %.
+// the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %, W8 (64 VGPRs,
+// spills) is 5-8 % slower.
 TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(lds, prune, stats);
     PT_V2(40, 4, 6) PT_V2(32, 4, 6) PT_V2(48, 4, 6) PT_V2(40, 4, 1)

@@ -41,6 +41,7 @@ struct TravStats {
 // space is a compile-time property of each kernel instantiation).
 struct SceneView {
     const DNode* nodes;
+    uint32_t node_stride;   // bytes between consecutive nodes: 64 in global memory, 80 in LDS (bank spreading)
     const DPrim* prims;
     const DNormals* normals;
     const DMaterial* materials;
@@ -73,7 +74,7 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
 // PRUNE=true also skips a child whose box entry lies beyond the closest hit.
 template <bool PRUNE>
 __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, int32_t* stk) {
-    const DNode* nd = sv.nodes + t.cur;
+    const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (uint32_t)t.cur * sv.node_stride;
     const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x
     const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy
     const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz
