@@ -71,6 +71,11 @@ void pt_host_camera_ray_data(const pt_camera* cam, int width, int height, float 
 /* Convenience: fill cam_* / width / height / spp / seed=1984 of *p from the camera (other fields zeroed). */
 void pt_host_default_params(const pt_camera* cam, int width, int height, int spp, pt_render_params* p);
 
+/* Image output (the reference never saves its framebuffer: main.cu:258-266).  fb = [height][width][3] floats, row 0 = top.
+ * PFM: lossless linear floats.  PPM: the reference's display encoding (sqrt gamma, 8 bit; opengl_display.cpp:104-111). */
+int pt_host_write_pfm(const char* path, const float* fb, int width, int height);
+int pt_host_write_ppm(const char* path, const float* fb, int width, int height);
+
 const char* pt_host_last_error(void);
 
 #ifdef __cplusplus

@@ -5,6 +5,6 @@ Product code only: host scene pipeline (host.py -> libpt_host.so), device librar
 oracle under oracle/ is test infrastructure and is never imported from here.
 """
 from .ctypes_defs import *  # noqa: F401,F403
-from .host import HostScene, camera_ray_data  # noqa: F401
+from .host import HostScene, camera_ray_data, read_pfm, write_image  # noqa: F401
 
 __version__ = "0.1.0"

@@ -18,9 +18,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = _build.HOST_LIB
-        if not os.path.exists(path):
-            _build.build_host()
+        path = _build.build_host()          # no-op when the in-tree .so is newer than its sources
         L = C.CDLL(path)
         vp = C.c_void_p
         L.pt_host_last_error.restype = C.c_char_p
@@ -44,6 +42,8 @@ def lib():
         L.pt_host_camera_ray_data.restype = None
         L.pt_host_default_params.argtypes = [C.POINTER(PtCamera), C.c_int, C.c_int, C.c_int, C.POINTER(PtRenderParams)]
         L.pt_host_default_params.restype = None
+        L.pt_host_write_pfm.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+        L.pt_host_write_ppm.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -183,3 +183,23 @@ def camera_ray_data(cam, width, height):
     out = (C.c_float * 12)()
     lib().pt_host_camera_ray_data(C.byref(cam), int(width), int(height), out)
     return np.array(out, dtype=np.float32).reshape(4, 3)
+
+
+def write_image(path, img):
+    """Save a frame [H, W, 3] float32: .pfm (lossless linear) or .ppm (sqrt-gamma 8 bit, as the reference displays it)."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("expected an [H, W, 3] image")
+    fn = lib().pt_host_write_pfm if str(path).endswith(".pfm") else lib().pt_host_write_ppm
+    rc = fn(str(path).encode(), _fptr(img), img.shape[1], img.shape[0])
+    if rc != PT_OK:
+        raise PtError(rc, f"cannot write {path}")
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4").reshape(h, w, 3)
+    return data[::-1].astype(np.float32)

@@ -252,3 +252,19 @@ def test_corrupt_pts_is_rejected(tmp_path):
     with pytest.raises(PtError) as e:
         HostScene.load(f)
     assert e.value.status == PT_ERR_PARSE
+
+
+def test_image_writers_roundtrip(tmp_path):
+    from pathtracer_cuda_interactive_amd import read_pfm, write_image
+    rng = np.random.default_rng(0)
+    img = (rng.random((5, 7, 3)) * 2).astype(np.float32)
+    img[0, 0] = (0.25, 4.0, -1.0)
+    write_image(tmp_path / "a.pfm", img)
+    assert_bit_equal(read_pfm(tmp_path / "a.pfm"), img, "pfm")
+    write_image(tmp_path / "a.ppm", img)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n7 5\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n7 5\n255\n"):], np.uint8).reshape(5, 7, 3)
+    assert px[0, 0].tolist() == [127, 255, 0]           # sqrt(0.25)=0.5 -> int(255.99*0.5)=127; clamp; negative -> NaN -> 0
+    with pytest.raises(PtError):
+        write_image(tmp_path / "no_such_dir" / "a.pfm", img)
