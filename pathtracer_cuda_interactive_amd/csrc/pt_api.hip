@@ -227,7 +227,8 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     ptd::Trav tv;
     tv.inv = ptm::mk(1, 1, 1);
     tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
-    tv.cur = kDone; tv.sp = 0;
+    tv.cur = kDone; tv.sp = 1;
+    ptd::stack_init(stk);
     ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
     ptm::Pcg rng;
     rng.state = 0; rng.inc = 1;
@@ -307,10 +308,23 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             }
         }
         // ---- traversal burst
-        if (INNER == 0) {
-            while (tv.cur >= 0) {
-                if (STATS) st.nodes++;
-                ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+        if (INNER < 0) {
+            // "vote" schedule: each step runs the step kind (inner-node visit or leaf test) that more lanes wait for
+#pragma unroll
+            for (int k = 0; k < -INNER; k++) {
+                const bool at_inner = tv.cur >= 0;
+                const bool at_leaf = tv.cur < 0 && tv.cur != kDone;
+                const int n_in = __popcll(__ballot(at_inner));
+                const int n_lf = __popcll(__ballot(at_leaf));
+                if (n_in >= n_lf) {
+                    if (at_inner) {
+                        if (STATS) st.nodes++;
+                        ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+                    }
+                } else if (at_leaf) {
+                    if (STATS) st.leaves++;
+                    ptd::leaf_step(sv, ray, tv, stk);
+                }
             }
         } else {
 #pragma unroll
@@ -320,10 +334,10 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                     ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
                 }
             }
-        }
-        if (tv.cur < 0 && tv.cur != kDone) {
-            if (STATS) st.leaves++;
-            ptd::leaf_step(sv, ray, tv, stk);
+            if (tv.cur < 0 && tv.cur != kDone) {
+                if (STATS) st.leaves++;
+                ptd::leaf_step(sv, ray, tv, stk);
+            }
         }
     }
     unsigned long long a = wave_sum(n_paths), b = wave_sum(n_segs);
@@ -477,7 +491,7 @@ struct pt_scene {
     int64_t opt_force_global = 0;
     int64_t opt_stats = 0;
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
-    int64_t opt_v2_thresh = 40, opt_v2_inner = 4, opt_v2_minw = 6;
+    int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
     // info of last launch
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
@@ -636,7 +650,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     dv.num_materials = d->num_materials;
     dv.num_emission = d->num_lights;
     dv.root_ref = root_ref;
-    dv.stack_cap = std::max(depth - 1, 1);
+    dv.stack_cap = std::max(depth - 1, 1) + 1;     // + the kDone sentinel at the bottom
     dv.bg[0] = d->background[0]; dv.bg[1] = d->background[1]; dv.bg[2] = d->background[2];
     S->bvh_depth = depth;
     S->scene_bytes = (uint32_t)std::min<size_t>(
@@ -682,13 +696,14 @@ TraceFn pick_v2_ti(bool lds, bool prune, bool stats) {
     return stats ? trace_kernel_v2<false, false, true, THRESH, INNER, MINW> : trace_kernel_v2<false, false, false, THRESH, INNER, MINW>;
 }
 
-// (thresh, inner, min-waves-per-SIMD) variants compiled in.  Measured on MI355X (tools/gpu_tune.py, round 1):
-// T40/I4/W6 is the fastest on cbox (4.90 ms) and bunny (11.8 ms); I8 and unbounded descent are slower, T56 starves
-// the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %, W8 (64 VGPRs,
-// spills) is 5-8 % slower.
+// (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps.
+// Measured on MI355X (tools/gpu_tune.py, profiles/r01_tune_round*.log): LDS-resident scenes are fastest with
+// T40 / vote-6 / W6 (cbox 4.58 ms), scenes in global memory with T32 / I4 / W6 (bunny 11.3 ms).  I8 and unbounded
+// descent are slower, T56 starves the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained
+// 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills) is 5-8 % slower.
 TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(lds, prune, stats);
-    PT_V2(40, 4, 6) PT_V2(32, 4, 6) PT_V2(48, 4, 6) PT_V2(40, 4, 1)
+    PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(48, 4, 6) PT_V2(40, 4, 1) PT_V2(32, -6, 6)
 #undef PT_V2
     return nullptr;
 }
@@ -696,7 +711,13 @@ TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner, 
 TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats);
 
 TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats) {
-    if (S->opt_kernel == 2) return pick_kernel_v2(lds, prune, stats, (int)S->opt_v2_thresh, (int)S->opt_v2_inner, (int)S->opt_v2_minw);
+    if (S->opt_kernel == 2) {
+        int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
+        if (t == 0) t = lds ? 40 : 32;
+        if (i == 0) i = lds ? -6 : 4;
+        if (w == 0) w = 6;
+        return pick_kernel_v2(lds, prune, stats, t, i, w);
+    }
     return pick_kernel_v1(lds, prune, stats);
 }
 

@@ -62,11 +62,14 @@ struct Trav {
     int32_t sp;        // entries on this lane's LDS stack column
 };
 
+// `stk` (this lane's column of the wave's LDS stack, entry k at stk[k*64]) must hold kDone in entry 0: stack_init().
+__device__ __forceinline__ void stack_init(int32_t* stk) { stk[0] = kDone; }
+
 __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, Trav& t) {
     t.inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
     t.best.t = FLT_MAX; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = -1;
     t.cur = sv.root_ref;           // scene.h:256: the root is pushed without a box test
-    t.sp = 0;
+    t.sp = 1;                      // entry 0 is the kDone sentinel
 }
 
 // One inner-node visit (requires t.cur >= 0): test both child boxes, descend into the nearer one,
@@ -101,21 +104,21 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
     }
     const int32_t L = __builtin_bit_cast(int32_t, d.x);
     const int32_t R = __builtin_bit_cast(int32_t, d.y);
-    if (hl && hr) {
-        // scene.h:281-289: visit the nearer box first; on a tie the right one
-        const bool left_first = ltn < rtn;
+    // scene.h:281-297: both hit -> visit the nearer box first (on a tie the right one) and keep the other on the
+    // stack; one hit -> descend into it; none -> pop.  The stack bottom holds a kDone sentinel (trav_begin), so a
+    // pop needs no emptiness test.  Written with selects so that only the push and the pop are masked regions.
+    const bool left_first = ltn < rtn;
+    const bool both = hl && hr;
+    const int32_t next = (hl && (!hr || left_first)) ? L : R;
+    if (both) {
         stk[t.sp * 64] = left_first ? R : L;
         t.sp++;
-        t.cur = left_first ? L : R;
-    } else if (hl) {
-        t.cur = L;
-    } else if (hr) {
-        t.cur = R;
-    } else if (t.sp > 0) {
+    }
+    if (hl || hr) {
+        t.cur = next;
+    } else {
         t.sp--;
         t.cur = stk[t.sp * 64];
-    } else {
-        t.cur = kDone;
     }
 }
 
@@ -177,8 +180,8 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             }
         }
     }
-    if (t.sp > 0) { t.sp--; t.cur = stk[t.sp * 64]; }
-    else t.cur = kDone;
+    t.sp--;                       // sentinel at the stack bottom: popping an empty stack yields kDone
+    t.cur = stk[t.sp * 64];
 }
 
 // Closest hit of one ray, run to completion (while-while loop): intersect() of scene.h:246-301.
@@ -186,6 +189,7 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
 template <bool PRUNE, bool STATS>
 __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, int32_t* stk, TravStats& st) {
     Trav t;
+    stack_init(stk);
     trav_begin(sv, ray, t);
     while (t.cur != kDone) {
         while (t.cur >= 0) {                    // descend through inner nodes until this lane holds a leaf

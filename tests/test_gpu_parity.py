@@ -55,7 +55,7 @@ def test_device_reproduces_golden_image(dscenes, path, trav, force_global, kerne
     assert_bit_equal(img, want, f"{name} trav={trav} global={force_global} kernel={kernel}")
 
 
-@pytest.mark.parametrize("thresh,inner,minw", [(40, 4, 6), (32, 4, 6), (48, 4, 6), (40, 4, 1)])
+@pytest.mark.parametrize("thresh,inner,minw", [(40, -6, 6), (32, 4, 6), (40, 4, 6), (48, 4, 6), (40, 4, 1), (32, -6, 6)])
 def test_scheduler_variants_are_bit_identical(oracle, dscenes, thresh, inner, minw):
     """The scheduling knobs of trace_kernel_v2 change WHEN a lane runs, never what it computes."""
     hs, d = load_scene("cbox")
@@ -68,14 +68,14 @@ def test_scheduler_variants_are_bit_identical(oracle, dscenes, thresh, inner, mi
         img = ds.render(p)
         c = ds.counters()
     finally:
-        for k, v in (("v2_thresh", 40), ("v2_inner", 4), ("v2_minw", 6), ("stats", 0)):
+        for k, v in (("v2_thresh", 0), ("v2_inner", 0), ("v2_minw", 0), ("stats", 0)):     # 0 = automatic choice
             ds.set_option(k, v)
     assert_bit_equal(img, want, f"T{thresh} I{inner} W{minw}")
     assert (c.paths, c.segments, c.node_visits) == (cnt.paths, cnt.segments, cnt.inner_pops)
     ds.set_option("v2_thresh", 17)
     with pytest.raises(PtError) as e:            # not compiled in
         ds.render(p)
-    ds.set_option("v2_thresh", 40)
+    ds.set_option("v2_thresh", 0)
     assert e.value.status == PT_ERR_INVALID_ARG
 
 

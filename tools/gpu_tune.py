@@ -19,7 +19,7 @@ CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480,
 
 def variants():
     yield ("v1", {"kernel": 1})
-    for (t, i, w) in ((40, 4, 6), (32, 4, 6), (48, 4, 6), (40, 4, 1)):
+    for (t, i, w) in ((0, 0, 0), (40, -6, 6), (32, 4, 6), (40, 4, 6), (48, 4, 6), (40, 4, 1), (32, -6, 6)):
         yield (f"v2 T{t} I{i} W{w}", {"kernel": 2, "v2_thresh": t, "v2_inner": i, "v2_minw": w})
 
 
