@@ -457,6 +457,21 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// Makes the scene's device current for the duration of a call and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            HIP_TRY(hipSetDevice(device));
+            switched = true;
+        }
+        return PT_OK;
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
+
 constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
 
@@ -744,7 +759,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     RowSel rows;
     int rc = select_rows(p, &rows);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(S->device));
+    DeviceGuard guard;
+    { int grc = guard.enter(S->device); if (grc) return grc; }
     if ((rc = S->counters.ensure(4))) return rc;
     HIP_TRY(hipMemsetAsync(S->counters.p, 0, 4 * sizeof(unsigned long long), stream));
     S->last_stream = stream;
@@ -873,7 +889,8 @@ int pt_scene_create(const pt_scene_desc* desc, pt_scene** out) {
 
 int pt_scene_destroy(pt_scene* S) {
     if (!S) return PT_OK;
-    (void)hipSetDevice(S->device);
+    DeviceGuard guard;
+    (void)guard.enter(S->device);
     if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
     S->nodes.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
     S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->work_counter.release(); S->counters.release();
@@ -903,7 +920,8 @@ int pt_render(pt_scene* S, const pt_render_params* p, float* fb, int fb_on_devic
     if (rc) return rc;
     if (p->width <= 0) return fail(PT_ERR_INVALID_ARG, "width must be positive");
     const size_t n = (size_t)rows.count * (size_t)p->width * 3;
-    HIP_TRY(hipSetDevice(S->device));
+    DeviceGuard guard;
+    { int grc = guard.enter(S->device); if (grc) return grc; }
     if ((rc = S->fb_tmp.ensure(n))) return rc;
     rc = launch_render(S, p, S->fb_tmp.p, 0, nullptr);
     if (rc) return rc;
@@ -914,7 +932,8 @@ int pt_render(pt_scene* S, const pt_render_params* p, float* fb, int fb_on_devic
 int pt_get_counters(pt_scene* S, pt_counters* out) {
     if (!S || !out) return fail(PT_ERR_INVALID_ARG, "null argument");
     std::memset(out, 0, sizeof *out);
-    HIP_TRY(hipSetDevice(S->device));
+    DeviceGuard guard;
+    { int grc = guard.enter(S->device); if (grc) return grc; }
     HIP_TRY(hipStreamSynchronize(S->last_stream));
     if (!S->counters.p) return PT_OK;
     unsigned long long c[4];
@@ -1017,7 +1036,8 @@ int pt_debug_math_host(int op, const float* x, const float* y, float* out0, floa
 int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, float* out_tuv, int32_t* out_prim) {
     if (!S || !rays || !out_tuv || !out_prim || n < 0) return fail(PT_ERR_INVALID_ARG, "bad argument");
     if (n == 0) return PT_OK;
-    HIP_TRY(hipSetDevice(S->device));
+    DeviceGuard guard;
+    { int grc = guard.enter(S->device); if (grc) return grc; }
     DevBuf<float> dr, dt;
     DevBuf<int32_t> dp;
     int rc;
