@@ -99,8 +99,12 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
     float rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
     bool hr = rtf >= fmax2(0.0f, rtn);
     if (PRUNE) {
-        hl = hl && !(ltn > t.best.t);
-        hr = hr && !(rtn > t.best.t);
+        // Skip a child whose box entry lies beyond the closest hit.  The 1e-5 relative slack keeps boxes whose
+        // entry is within rounding of the hit: a triangle's Moeller-Trumbore t and its (possibly flat) box's slab
+        // entry round differently, and without slack one cbox path in ~2e7 lost its true closest hit.
+        const float lim = t.best.t + t.best.t * 1e-5f;
+        hl = hl && !(ltn > lim);
+        hr = hr && !(rtn > lim);
     }
     const int32_t L = __builtin_bit_cast(int32_t, d.x);
     const int32_t R = __builtin_bit_cast(int32_t, d.y);
