@@ -69,8 +69,23 @@ def build_hip(force=False, extra_flags=()):
     return HIP_LIB
 
 
+EXAMPLE_BIN = os.path.join(REPO_DIR, "examples", "render_main")
+
+
+def build_example(force=False):
+    """C++ front-end on the bare C ABI (examples/render_main.cpp): proves the boundary needs no Python."""
+    src = os.path.join(REPO_DIR, "examples", "render_main.cpp")
+    if force or _newer(EXAMPLE_BIN, [src, HOST_LIB, HIP_LIB] + _glob(INCLUDE, (".h",))):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-I", INCLUDE, src, "-L", PKG_DIR, "-lpt_host", "-lpt_hip",
+              "-Wl,-rpath," + PKG_DIR, "-Wl,-rpath,$ORIGIN/../pathtracer_cuda_interactive_amd", "-Wl,-rpath,/opt/rocm/lib",
+              "-o", EXAMPLE_BIN])
+    return EXAMPLE_BIN
+
+
 def build_all(force=False):
-    return build_host(force), build_hip(force)
+    out = build_host(force), build_hip(force)
+    build_example(force)
+    return out
 
 
 if __name__ == "__main__":

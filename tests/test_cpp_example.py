@@ -1,0 +1,35 @@
+"""examples/render_main.cpp: the offline path of the reference's main() on the bare C ABI (no Python in the loop)."""
+import subprocess
+
+import numpy as np
+import pytest
+from conftest import SCENES, _gpu_available, assert_bit_equal, load_scene
+
+from pathtracer_cuda_interactive_amd import _build, read_pfm
+
+
+@pytest.fixture(scope="module")
+def binary():
+    _build.build_host()
+    return _build.build_example()
+
+
+@pytest.mark.skipif(_gpu_available(), reason="only meaningful on a box without a GPU")
+def test_example_fails_loudly_without_a_gpu(binary, tmp_path):
+    r = subprocess.run([binary, f"{SCENES}/cbox.pts", str(tmp_path / "x.pfm"), "16", "12", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    assert subprocess.run([binary], capture_output=True).returncode == 2            # usage
+    r = subprocess.run([binary, "/nonexistent.xml", "x.pfm"], capture_output=True, text=True)
+    assert r.returncode == 1 and "scene load failed" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cbox", "scene1"])
+def test_example_renders_the_oracle_image(oracle, binary, tmp_path, name):
+    out = tmp_path / "frame.pfm"
+    r = subprocess.run([binary, f"{SCENES}/{name}.pts", str(out), "48", "36", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "GPU rendering took" in r.stdout and "Maximum BVH depth" in r.stdout
+    hs, d = load_scene(name)
+    want, _ = oracle.render(d, hs.render_params(48, 36, 5))
+    assert_bit_equal(read_pfm(out), want, name)
