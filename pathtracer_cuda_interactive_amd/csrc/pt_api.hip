@@ -41,6 +41,79 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+
+// ---- work distribution ---------------------------------------------------------------------------------------
+// The frame is cut into rp.num_regions bands of rows.  A wave first serves the band that belongs to the XCD it runs
+// on (HW_REG_XCC_ID), so the rays an XCD's L2 sees start in 1/8 of the image; when that band is exhausted it steals
+// from the next ones.  Each band has its own work counter (128 B apart); a wave reserves kChunk items per atomic.
+// Placement only affects speed: every work item is rendered exactly once whatever XCD picks it up.
+constexpr int kCounterStride = 32;   // uint32 slots between region counters (one 128-B line each)
+
+struct WorkFeed {
+    uint32_t cur, end;       // reserved chunk [cur, end) of region-local item ids
+    uint32_t region;
+    uint32_t tried;          // regions found exhausted so far
+    bool exhausted;
+};
+
+__device__ __forceinline__ uint32_t region_rows(const RenderDev& rp, uint32_t region) {
+    const uint32_t first = region * (uint32_t)rp.rows_per_region;
+    const uint32_t nrows = (uint32_t)rp.num_rows;
+    return first >= nrows ? 0u : min((uint32_t)rp.rows_per_region, nrows - first);
+}
+
+__device__ __forceinline__ void feed_init(WorkFeed& f, const RenderDev& rp) {
+    f.cur = 0; f.end = 0; f.tried = 0; f.exhausted = false;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u;     // hwreg(HW_REG_XCC_ID, 0, 4)
+    f.region = xcc % (uint32_t)rp.num_regions;
+}
+
+// Wave-uniform.  Makes sure a non-empty chunk is reserved unless every region is exhausted.
+__device__ __forceinline__ void feed_reserve(WorkFeed& f, const RenderDev& rp, uint32_t* work_counters, int lane) {
+    while (f.cur >= f.end && !f.exhausted) {
+        const uint32_t total = region_rows(rp, f.region) * (uint32_t)rp.width * (uint32_t)rp.spp_pass;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&work_counters[f.region * kCounterStride], kChunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base < total) {
+            f.cur = base;
+            f.end = min(base + kChunk, total);
+        } else if (++f.tried >= (uint32_t)rp.num_regions) {
+            f.exhausted = true;
+        } else {
+            f.region = (f.region + 1) % (uint32_t)rp.num_regions;
+        }
+    }
+}
+
+struct PathStart {
+    ptd::Ray ray;
+    ptm::Pcg rng;
+    uint32_t sample_index;   // slot in the sample-major scratch buffer
+};
+
+// main.cu:32-44 for region-local work item `item` of `region`: (sample, pixel) -> PCG stream, jitter, primary ray.
+__device__ __forceinline__ PathStart start_path(const RenderDev& rp, uint32_t region, uint32_t item) {
+    const uint32_t npix_r = region_rows(rp, region) * (uint32_t)rp.width;
+    const uint32_t s_local = item / npix_r;
+    const uint32_t pix_r = item - s_local * npix_r;
+    const uint32_t rr = pix_r / (uint32_t)rp.width;
+    const int i = (int)(pix_r - rr * (uint32_t)rp.width);
+    const uint32_t local_row = region * (uint32_t)rp.rows_per_region + rr;
+    const int j = rp.row_begin + (int)local_row * rp.row_step;
+    const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;
+    const uint64_t stream = pixel_index * (uint64_t)rp.stream_stride + (uint64_t)(rp.sample_base + (int)s_local);
+    PathStart ps;
+    ps.rng = ptm::pcg_init(stream, rp.seed);
+    const float ru = ptm::pcg_float(ps.rng);
+    const float u = ((float)i + ru) / (float)rp.width;
+    const float rv = ptm::pcg_float(ps.rng);
+    const float v = ((float)j + rv) / (float)rp.height;
+    ps.ray = ptd::primary_ray(rp, u, v);
+    ps.sample_index = s_local * rp.npix + local_row * (uint32_t)rp.width + (uint32_t)i;
+    return ps;
+}
+
 __device__ __forceinline__ void stage_to_lds(void* dst, const void* src, uint32_t bytes) {
     float4* d = reinterpret_cast<float4*>(dst);
     const float4* s = reinterpret_cast<const float4*>(src);
@@ -90,8 +163,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
     const int wave = threadIdx.x >> 6;
     int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
 
-    uint32_t chunk_cur = 0, chunk_end = 0;
-    bool exhausted = false;
+    WorkFeed feed;
+    feed_init(feed, rp);
     bool alive = false;
     ptd::Ray ray;
     ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
@@ -108,46 +181,27 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
         // ---- refill dead lanes with new paths
         const unsigned long long need = __ballot(!alive);
         if (need) {
-            if (chunk_cur >= chunk_end && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_counter, kChunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= rp.total_work) exhausted = true;
-                else { chunk_cur = base; chunk_end = min(base + kChunk, rp.total_work); }
-            }
-            const uint32_t avail = chunk_end - chunk_cur;
+            feed_reserve(feed, rp, work_counter, lane);
+            const uint32_t avail = feed.end - feed.cur;
             if (avail) {
                 const uint32_t rank = lane_rank(need);
                 const uint32_t n = (uint32_t)__popcll(need);
                 if (!alive && rank < avail) {
-                    // main.cu:32-44 for work item w = (sample, pixel)
-                    const uint32_t w = chunk_cur + rank;
-                    const uint32_t s_local = w / rp.npix;
-                    const uint32_t pix = w - s_local * rp.npix;
-                    const uint32_t r = pix / (uint32_t)rp.width;
-                    const int i = (int)(pix - r * (uint32_t)rp.width);
-                    const int j = rp.row_begin + (int)r * rp.row_step;
-                    const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;
-                    const uint64_t stream = pixel_index * (uint64_t)rp.stream_stride +
-                                            (uint64_t)(rp.sample_base + (int)s_local);
-                    rng = ptm::pcg_init(stream, rp.seed);
-                    const float ru = ptm::pcg_float(rng);
-                    const float u = ((float)i + ru) / (float)rp.width;
-                    const float rv = ptm::pcg_float(rng);
-                    const float v = ((float)j + rv) / (float)rp.height;
-                    ray = ptd::primary_ray(rp, u, v);
+                    const PathStart ps = start_path(rp, feed.region, feed.cur + rank);
+                    ray = ps.ray;
+                    rng = ps.rng;
+                    my_w = ps.sample_index;
                     L = ptm::mk(0, 0, 0);
                     T = ptm::mk(1, 1, 1);
                     depth = 0;
-                    my_w = w;
                     alive = true;
                     n_paths++;
                 }
-                chunk_cur += min(n, avail);
+                feed.cur += min(n, avail);
             }
         }
         if (!__any(alive)) {
-            if (exhausted) break;
+            if (feed.exhausted) break;
             continue;
         }
         // ---- one path segment per live lane (radiance.cuh:24-75)
@@ -219,8 +273,8 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     const int wave = threadIdx.x >> 6;
     int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
 
-    uint32_t chunk_cur = 0, chunk_end = 0;
-    bool exhausted = false;
+    WorkFeed feed;
+    feed_init(feed, rp);
     bool alive = false;
     ptd::Ray ray;
     ray.org = ptm::mk(0, 0, 0); ray.dir = ptm::mk(0, 0, 1); ray.tnear = 0; ray.tfar = 0;
@@ -241,7 +295,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     for (;;) {
         const bool idle = tv.cur == kDone;
         const unsigned long long idle_mask = __ballot(idle);
-        const bool work_left = !(exhausted && chunk_cur >= chunk_end);        // wave-uniform
+        const bool work_left = !(feed.exhausted && feed.cur >= feed.end);        // wave-uniform
         const int n_pend = __popcll(__ballot(idle && (alive || work_left)));
         if (n_pend >= THRESH || idle_mask == ~0ull) {
             if (n_pend == 0) break;          // every lane idle, no live path, no work left
@@ -264,41 +318,23 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             // (2) refill dead lanes (main.cu:32-44)
             const unsigned long long need = __ballot(idle && !alive);
             if (need) {
-                if (chunk_cur >= chunk_end && !exhausted) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(work_counter, kChunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= rp.total_work) exhausted = true;
-                    else { chunk_cur = base; chunk_end = min(base + kChunk, rp.total_work); }
-                }
-                const uint32_t avail = chunk_end - chunk_cur;
+                feed_reserve(feed, rp, work_counter, lane);
+                const uint32_t avail = feed.end - feed.cur;
                 if (avail) {
                     const uint32_t rank = lane_rank(need);
                     const uint32_t n = (uint32_t)__popcll(need);
                     if (idle && !alive && rank < avail) {
-                        const uint32_t w = chunk_cur + rank;
-                        const uint32_t s_local = w / rp.npix;
-                        const uint32_t pix = w - s_local * rp.npix;
-                        const uint32_t r = pix / (uint32_t)rp.width;
-                        const int i = (int)(pix - r * (uint32_t)rp.width);
-                        const int j = rp.row_begin + (int)r * rp.row_step;
-                        const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;
-                        const uint64_t stream = pixel_index * (uint64_t)rp.stream_stride +
-                                                (uint64_t)(rp.sample_base + (int)s_local);
-                        rng = ptm::pcg_init(stream, rp.seed);
-                        const float ru = ptm::pcg_float(rng);
-                        const float u = ((float)i + ru) / (float)rp.width;
-                        const float rv = ptm::pcg_float(rng);
-                        const float v = ((float)j + rv) / (float)rp.height;
-                        ray = ptd::primary_ray(rp, u, v);
+                        const PathStart ps = start_path(rp, feed.region, feed.cur + rank);
+                        ray = ps.ray;
+                        rng = ps.rng;
+                        my_w = ps.sample_index;
                         L = ptm::mk(0, 0, 0);
                         T = ptm::mk(1, 1, 1);
                         depth = 0;
-                        my_w = w;
                         alive = true;
                         n_paths++;
                     }
-                    chunk_cur += min(n, avail);
+                    feed.cur += min(n, avail);
                 }
             }
             // (3) start the next traversal (scene.h:247-256)
@@ -505,6 +541,7 @@ struct pt_scene {
     int64_t opt_scratch_bytes = 0;
     int64_t opt_force_global = 0;
     int64_t opt_stats = 0;
+    int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
     // info of last launch
@@ -780,7 +817,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (mode == 2 && n_pass > 1)
         return fail(PT_ERR_UNSUPPORTED, "pt_render_accumulate: spp of one call must fit the scratch budget (single pass)");
     if (n_pass > 1 && (rc = S->accum.ensure(npix * 3))) return rc;
-    if ((rc = S->work_counter.ensure(1))) return rc;
+    if ((rc = S->work_counter.ensure(8 * kCounterStride))) return rc;
 
     const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
@@ -818,6 +855,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         rd.rr_depth = p->rr_depth >= 0 ? p->rr_depth : 5;
         rd.npix = (uint32_t)npix;
         rd.total_work = (uint32_t)(npix * (uint64_t)sn);
+        rd.num_regions = S->opt_xcd_regions > 0 ? (int)std::min<int64_t>(S->opt_xcd_regions, 8) : 8;
+        rd.rows_per_region = (rows.count + rd.num_regions - 1) / rd.num_regions;
 
         const uint64_t blocks_needed = (rd.total_work + kBlock - 1) / kBlock;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)S->num_cus * bpc, blocks_needed));
@@ -828,7 +867,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         HIP_TRY(hipEventCreate(&pe.t1));
         HIP_TRY(hipEventCreate(&pe.r1));
         S->pass_events.push_back(pe);
-        HIP_TRY(hipMemsetAsync(S->work_counter.p, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(S->work_counter.p, 0, 8 * kCounterStride * sizeof(uint32_t), stream));
         HIP_TRY(hipEventRecord(pe.t0, stream));
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
                            S->work_counter.p, S->counters.p);
@@ -961,6 +1000,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "scratch_bytes") S->opt_scratch_bytes = value;
     else if (k == "force_global") S->opt_force_global = value;
     else if (k == "stats") S->opt_stats = value;
+    else if (k == "xcd_regions") S->opt_xcd_regions = value;
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
     else if (k == "v2_inner") S->opt_v2_inner = value;

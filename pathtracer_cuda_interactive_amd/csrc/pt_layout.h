@@ -76,6 +76,8 @@ struct RenderDev {
     int32_t max_depth, rr_depth;
     uint32_t total_work;            // num_rows*width*spp_pass
     uint32_t npix;                  // num_rows*width
+    int32_t num_regions;            // row bands with their own work counter (XCD affinity), 1..8
+    int32_t rows_per_region;        // ceil(num_rows / num_regions)
 };
 
 // LDS carve-up of the trace kernel (all offsets in bytes, 16-B aligned)

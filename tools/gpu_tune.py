@@ -18,9 +18,10 @@ CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480,
 
 
 def variants():
-    yield ("v1", {"kernel": 1})
+    yield ("v1", {"kernel": 1, "xcd_regions": 0})
+    yield ("v2 auto 1queue", {"kernel": 2, "v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "xcd_regions": 1})
     for (t, i, w) in ((0, 0, 0), (40, -6, 6), (32, 4, 6), (40, 4, 6), (48, 4, 6), (40, 4, 1), (32, -6, 6)):
-        yield (f"v2 T{t} I{i} W{w}", {"kernel": 2, "v2_thresh": t, "v2_inner": i, "v2_minw": w})
+        yield (f"v2 T{t} I{i} W{w}", {"kernel": 2, "v2_thresh": t, "v2_inner": i, "v2_minw": w, "xcd_regions": 0})
 
 
 def main():
@@ -55,7 +56,7 @@ def main():
                     regs[label] = (ds.info("vgprs_pruned" if trav == PT_TRAVERSAL_PRUNED else "vgprs"), ds.info("occupancy"))
             for label, _ in vs:
                 t = np.array(times[label][1:])
-                print(f"{name:7s} {tn:6s} {label:13s} parity={'OK ' if ok[label] else 'BAD'} vgpr={regs[label][0]:3d} occ={regs[label][1]} "
+                print(f"{name:7s} {tn:6s} {label:15s} parity={'OK ' if ok[label] else 'BAD'} vgpr={regs[label][0]:3d} occ={regs[label][1]} "
                       f"median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  -> {segs / np.median(t) / 1e3:9.1f} Msamples/s", flush=True)
         ds.close()
 
