@@ -1,0 +1,97 @@
+// Microbenchmark: cost of fetching random 64-byte BVH nodes with one ray per lane.
+//   A: every lane loads its own node with 4 x global_load_dwordx4 (what inner_step does)
+//   B: quad-cooperative: the 4 lanes of a quad load the 4 x 16 B pieces of ONE node per instruction (coalesced 64 B),
+//      4 instructions cover the quad's 4 nodes; data is then exchanged inside the quad with DPP
+//   C: like A but each lane loads only 16 B (lower bound for "one request per lane")
+// Table size and dependent-chain length are parameters; the address of step i+1 depends on the data of step i,
+// like a traversal.   hipcc --offload-arch=gfx950 -O3 gather_nodes.hip -o gather_nodes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gather(const float4* __restrict__ nodes, uint32_t n_nodes, int steps, uint32_t* out) {
+    uint32_t idx = mix(blockIdx.x * 256u + threadIdx.x) % n_nodes;
+    float acc = 0.f;
+    const int q = threadIdx.x & 3;
+    for (int s = 0; s < steps; s++) {
+        float4 a, b, c, d;
+        if (MODE == 0) {
+            const float4* p = nodes + (size_t)idx * 4;
+            a = p[0]; b = p[1]; c = p[2]; d = p[3];
+        } else if (MODE == 2) {
+            const float4* p = nodes + (size_t)idx * 4;
+            a = p[0]; b = a; c = a; d = a;
+        } else {
+            // node index of quad lane k, broadcast inside the quad
+            const uint32_t i0 = __builtin_amdgcn_mov_dpp(idx, 0x00, 0xf, 0xf, true);   // quad_perm [0,0,0,0]
+            const uint32_t i1 = __builtin_amdgcn_mov_dpp(idx, 0x55, 0xf, 0xf, true);   // [1,1,1,1]
+            const uint32_t i2 = __builtin_amdgcn_mov_dpp(idx, 0xaa, 0xf, 0xf, true);   // [2,2,2,2]
+            const uint32_t i3 = __builtin_amdgcn_mov_dpp(idx, 0xff, 0xf, 0xf, true);   // [3,3,3,3]
+            const float4 m0 = nodes[(size_t)i0 * 4 + q];     // piece q of node 0
+            const float4 m1 = nodes[(size_t)i1 * 4 + q];
+            const float4 m2 = nodes[(size_t)i2 * 4 + q];
+            const float4 m3 = nodes[(size_t)i3 * 4 + q];
+            // lane q needs piece j of node q = register m_q of lane j.  Select m_q locally, then fetch from lane j.
+            const float4 mine = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;   // piece q of MY node (diagonal)
+            // rotation r: lane q gets piece (q+r)%4 of its node from lane (q+r)%4, which must offer m_{q} ... the offered
+            // register depends on the READER, so each source offers the register of the lane r positions "before" it.
+            auto offer = [&](int r) { const int t = (q - r) & 3; return t == 0 ? m0 : t == 1 ? m1 : t == 2 ? m2 : m3; };
+            const float4 o1 = offer(1), o2 = offer(2), o3 = offer(3);
+#define ROT4(v, ctrl) make_float4( \
+    __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v).x), ctrl, 0xf, 0xf, true)), \
+    __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v).y), ctrl, 0xf, 0xf, true)), \
+    __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v).z), ctrl, 0xf, 0xf, true)), \
+    __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v).w), ctrl, 0xf, 0xf, true)))
+            const float4 g1 = ROT4(o1, 0x39);   // quad_perm [1,2,3,0]: lane q reads lane q+1
+            const float4 g2 = ROT4(o2, 0x4e);   // [2,3,0,1]
+            const float4 g3 = ROT4(o3, 0x93);   // [3,0,1,2]
+            // g_r = piece (q+r)%4 of my node; put pieces in order
+            const float4 p0 = q == 0 ? mine : q == 1 ? g3 : q == 2 ? g2 : g1;
+            const float4 p1 = q == 1 ? mine : q == 2 ? g3 : q == 3 ? g2 : g1;
+            const float4 p2 = q == 2 ? mine : q == 3 ? g3 : q == 0 ? g2 : g1;
+            const float4 p3 = q == 3 ? mine : q == 0 ? g3 : q == 1 ? g2 : g1;
+            a = p0; b = p1; c = p2; d = p3;
+        }
+        acc += a.x + b.y + c.z;
+        idx = mix(__builtin_bit_cast(uint32_t, d.x) + idx) % n_nodes;    // dependent chain (d.x holds the node's own index)
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = idx + (uint32_t)acc;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t n_nodes = argc > 1 ? atoi(argv[1]) : 576186;   // bunny: 36.9 MB of nodes
+    const int steps = argc > 2 ? atoi(argv[2]) : 64;
+    std::vector<float> h((size_t)n_nodes * 16);
+    for (uint32_t i = 0; i < n_nodes; i++)
+        for (int k = 0; k < 16; k++) h[(size_t)i * 16 + k] = (k == 12) ? __builtin_bit_cast(float, i * 2654435761u) : float(i % 97) + k;
+    float4* d; uint32_t* out;
+    const int blocks = 256 * 6;
+    CHECK(hipMalloc(&d, h.size() * 4)); CHECK(hipMalloc(&out, blocks * 256 * 4));
+    CHECK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<uint32_t> r0(blocks * 256), r1(blocks * 256);
+    for (int mode = 0; mode < 3; mode++) {
+        float best = 1e9;
+        for (int rep = 0; rep < 5; rep++) {
+            CHECK(hipEventRecord(e0));
+            if (mode == 0) gather<0><<<blocks, 256>>>(d, n_nodes, steps, out);
+            else if (mode == 1) gather<1><<<blocks, 256>>>(d, n_nodes, steps, out);
+            else gather<2><<<blocks, 256>>>(d, n_nodes, steps, out);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        CHECK(hipMemcpy(mode == 0 ? r0.data() : r1.data(), out, blocks * 256 * 4, hipMemcpyDeviceToHost));
+        const double fetches = double(blocks) * 256 * steps;
+        printf("mode %d (%s): %.3f ms, %.2f G node fetches/s, %.1f cycles per wave-step per CU @2.4GHz\n", mode,
+               mode == 0 ? "own node, 4 x dwordx4" : mode == 1 ? "quad-cooperative + DPP transpose" : "own node, 1 x dwordx4 only",
+               best, fetches / best / 1e6, best * 1e-3 * 2.4e9 / (fetches / 64 / 256));
+        if (mode == 1) { size_t bad = 0; for (size_t i = 0; i < r0.size(); i++) bad += r0[i] != r1[i]; printf("  mode 1 vs mode 0 mismatches: %zu\n", bad); }
+    }
+    return 0;
+}
