@@ -17,6 +17,12 @@ DATA = os.path.join(TESTS, "data")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The native libraries are built in-tree and git-ignored: a fresh checkout has none.  Build what is missing
+    # (hipcc cross-compiles gfx950 without a GPU); never rebuild the HIP library that travelled to the GPU box.
+    from pathtracer_cuda_interactive_amd import _build
+    _build.build_host()
+    if not os.path.exists(_build.HIP_LIB):
+        _build.build_hip()
 
 
 def _gpu_available():
