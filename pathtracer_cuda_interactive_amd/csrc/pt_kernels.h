@@ -1,0 +1,438 @@
+// pt_kernels.h — the gfx950 kernels of the path tracer (included only by pt_api.hip).
+//
+//   trace_kernel_v2<LDS_SCENE,PRUNE,STATS,THRESH,INNER,MINW>   persistent wavefront path tracer with decoupled
+//        traversal / shading scheduling (default).  Replaces render + setup_rand (main.cu:30-62) and all they call.
+//   trace_kernel<LDS_SCENE,PRUNE,STATS>   the simpler segment-synchronous schedule (option "kernel" = 1).
+//   resolve_kernel     ordered per-pixel sum of the per-sample radiances (main.cu:47,50 / 72-86).
+//   intersect_kernel, math_kernel   test hooks behind pt_debug_*.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_layout.h"
+#include "pt_math.h"
+#include "pt_trace.h"
+
+namespace ptk {
+
+using namespace ptl;
+
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr uint32_t kChunk = 256;     // work items a wave reserves per atomic
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+
+// ---- work distribution ---------------------------------------------------------------------------------------
+// The frame is cut into rp.num_regions bands of rows.  A wave first serves the band that belongs to the XCD it runs
+// on (HW_REG_XCC_ID), so the rays an XCD's L2 sees start in 1/8 of the image; when that band is exhausted it steals
+// from the next ones.  Each band has its own work counter (128 B apart); a wave reserves kChunk items per atomic.
+// Placement only affects speed: every work item is rendered exactly once whatever XCD picks it up.
+constexpr int kCounterStride = 32;   // uint32 slots between region counters (one 128-B line each)
+
+struct WorkFeed {
+    uint32_t cur, end;       // reserved chunk [cur, end) of region-local item ids
+    uint32_t region;
+    uint32_t tried;          // regions found exhausted so far
+    bool exhausted;
+};
+
+__device__ __forceinline__ uint32_t region_rows(const RenderDev& rp, uint32_t region) {
+    const uint32_t first = region * (uint32_t)rp.rows_per_region;
+    const uint32_t nrows = (uint32_t)rp.num_rows;
+    return first >= nrows ? 0u : min((uint32_t)rp.rows_per_region, nrows - first);
+}
+
+__device__ __forceinline__ void feed_init(WorkFeed& f, const RenderDev& rp) {
+    f.cur = 0; f.end = 0; f.tried = 0; f.exhausted = false;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u;     // hwreg(HW_REG_XCC_ID, 0, 4)
+    f.region = xcc % (uint32_t)rp.num_regions;
+}
+
+// Wave-uniform.  Makes sure a non-empty chunk is reserved unless every region is exhausted.
+__device__ __forceinline__ void feed_reserve(WorkFeed& f, const RenderDev& rp, uint32_t* work_counters, int lane) {
+    while (f.cur >= f.end && !f.exhausted) {
+        const uint32_t total = region_rows(rp, f.region) * (uint32_t)rp.width * (uint32_t)rp.spp_pass;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&work_counters[f.region * kCounterStride], kChunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base < total) {
+            f.cur = base;
+            f.end = min(base + kChunk, total);
+        } else if (++f.tried >= (uint32_t)rp.num_regions) {
+            f.exhausted = true;
+        } else {
+            f.region = (f.region + 1) % (uint32_t)rp.num_regions;
+        }
+    }
+}
+
+struct PathStart {
+    ptd::Ray ray;
+    ptm::Pcg rng;
+    uint32_t sample_index;   // slot in the sample-major scratch buffer
+};
+
+// main.cu:32-44 for region-local work item `item` of `region`: (sample, pixel) -> PCG stream, jitter, primary ray.
+__device__ __forceinline__ PathStart start_path(const RenderDev& rp, uint32_t region, uint32_t item) {
+    const uint32_t npix_r = region_rows(rp, region) * (uint32_t)rp.width;
+    const uint32_t s_local = item / npix_r;
+    const uint32_t pix_r = item - s_local * npix_r;
+    const uint32_t rr = pix_r / (uint32_t)rp.width;
+    const int i = (int)(pix_r - rr * (uint32_t)rp.width);
+    const uint32_t local_row = region * (uint32_t)rp.rows_per_region + rr;
+    const int j = rp.row_begin + (int)local_row * rp.row_step;
+    const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;
+    const uint64_t stream = pixel_index * (uint64_t)rp.stream_stride + (uint64_t)(rp.sample_base + (int)s_local);
+    PathStart ps;
+    ps.rng = ptm::pcg_init(stream, rp.seed);
+    const float ru = ptm::pcg_float(ps.rng);
+    const float u = ((float)i + ru) / (float)rp.width;
+    const float rv = ptm::pcg_float(ps.rng);
+    const float v = ((float)j + rv) / (float)rp.height;
+    ps.ray = ptd::primary_ray(rp, u, v);
+    ps.sample_index = s_local * rp.npix + local_row * (uint32_t)rp.width + (uint32_t)i;
+    return ps;
+}
+
+__device__ __forceinline__ void stage_to_lds(void* dst, const void* src, uint32_t bytes) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    const float4* s = reinterpret_cast<const float4*>(src);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+
+// Node placement in LDS.  An 80-B stride (16 bank positions instead of 4 for ds_read_b128) was measured on cbox:
+// no gain within run-to-run noise (5.02 vs 4.90 ms, tools/gpu_tune.py round 3) although 41 % of LDS cycles are
+// bank conflicts — the kernel is VALU-issue bound, not LDS bound — so nodes stay densely packed.
+constexpr uint32_t kLdsNodeStride = 64;
+__device__ __forceinline__ void stage_nodes_to_lds(void* dst, const DNode* src, uint32_t n) {
+    const float4* s = reinterpret_cast<const float4*>(src);
+    for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x)
+        *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(dst) + (i >> 2) * kLdsNodeStride + (i & 3) * 16) = s[i];
+}
+
+// The scene as this kernel instantiation sees it: staged into LDS by the whole workgroup (small scenes) or read in
+// place from global memory.  Must be called by every thread of the block (it contains a __syncthreads()).
+template <bool LDS_SCENE>
+__device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, const LdsPlan& lp, unsigned char* smem) {
+    ptd::SceneView sv;
+    if (LDS_SCENE) {
+        stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
+        stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
+        stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
+        stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
+        stage_to_lds(smem + lp.emis_off, scn.emission, (uint32_t)scn.num_emission * sizeof(DEmission));
+        __syncthreads();
+        sv.nodes = reinterpret_cast<const DNode*>(smem + lp.nodes_off);
+        sv.prims = reinterpret_cast<const DPrim*>(smem + lp.prims_off);
+        sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
+        sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
+        sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
+        sv.node_stride = kLdsNodeStride;
+    } else {
+        sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
+        sv.materials = scn.materials; sv.emission = scn.emission;
+        sv.node_stride = sizeof(DNode);
+    }
+    sv.num_emission = scn.num_emission;
+    sv.root_ref = scn.root_ref;
+    sv.bg = ptm::mk(scn.bg[0], scn.bg[1], scn.bg[2]);
+    return sv;
+}
+
+// pt_counters: per-wave sums, one atomic per wave and counter.
+template <bool STATS>
+__device__ __forceinline__ void flush_counters(unsigned long long* counters, int lane, uint32_t n_paths, uint32_t n_segs,
+                                               const ptd::TravStats& st) {
+    const unsigned long long a = wave_sum(n_paths), b = wave_sum(n_segs);
+    const unsigned long long c = STATS ? wave_sum(st.nodes) : 0ull, d = STATS ? wave_sum(st.leaves) : 0ull;
+    if (lane == 0) {
+        atomicAdd(&counters[0], a);
+        atomicAdd(&counters[1], b);
+        if (STATS) { atomicAdd(&counters[2], c); atomicAdd(&counters[3], d); }
+    }
+}
+
+template <bool LDS_SCENE, bool PRUNE, bool STATS>
+__global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev rp, LdsPlan lp,
+                                                       float4* __restrict__ samples,
+                                                       uint32_t* __restrict__ work_counter,
+                                                       unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ptd::SceneView sv = make_scene_view<LDS_SCENE>(scn, lp, smem);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
+
+    WorkFeed feed;
+    feed_init(feed, rp);
+    bool alive = false;
+    ptd::Ray ray;
+    ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
+    ptm::Pcg rng;
+    rng.state = 0; rng.inc = 1;
+    int depth = 0;
+    uint32_t my_w = 0;
+    uint32_t n_paths = 0, n_segs = 0;
+    ptd::TravStats st;
+    st.nodes = 0; st.leaves = 0;
+    ray.org = ptm::mk(0, 0, 0); ray.dir = ptm::mk(0, 0, 1); ray.tnear = 0; ray.tfar = 0;
+
+    for (;;) {
+        // ---- refill dead lanes with new paths
+        const unsigned long long need = __ballot(!alive);
+        if (need) {
+            feed_reserve(feed, rp, work_counter, lane);
+            const uint32_t avail = feed.end - feed.cur;
+            if (avail) {
+                const uint32_t rank = lane_rank(need);
+                const uint32_t n = (uint32_t)__popcll(need);
+                if (!alive && rank < avail) {
+                    const PathStart ps = start_path(rp, feed.region, feed.cur + rank);
+                    ray = ps.ray;
+                    rng = ps.rng;
+                    my_w = ps.sample_index;
+                    L = ptm::mk(0, 0, 0);
+                    T = ptm::mk(1, 1, 1);
+                    depth = 0;
+                    alive = true;
+                    n_paths++;
+                }
+                feed.cur += min(n, avail);
+            }
+        }
+        if (!__any(alive)) {
+            if (feed.exhausted) break;
+            continue;
+        }
+        // ---- one path segment per live lane (radiance.cuh:24-75)
+        if (alive) {
+            n_segs++;
+            const ptd::Hit h = ptd::intersect<PRUNE, STATS>(sv, ray, stk, st);
+            bool cont = false;
+            if (h.prim < 0) {
+                L = L + T * sv.bg;                          // radiance.cuh:27-30
+            } else {
+                const ptd::Surface sf = ptd::make_surface(sv, ray, h);
+                cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                depth++;
+                if (depth >= rp.max_depth) cont = false;
+            }
+            if (!cont) {
+                samples[my_w] = make_float4(L.x, L.y, L.z, 0.0f);
+                alive = false;
+            }
+        }
+    }
+    // ---- work counters (pt_counters)
+    flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
+}
+
+// trace_kernel_v2 — same work, different schedule: traversal is decoupled from shading.
+// Every lane runs a small state machine {traversing | waiting for the scheduler phase}.  The wave keeps
+// executing traversal steps (INNER inner-node visits + at most one leaf test per iteration) for the lanes that
+// still traverse; lanes whose traversal finished wait until at least THRESH lanes can make progress in the
+// scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
+// (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
+// the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
+template <bool LDS_SCENE, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
+                                                          float4* __restrict__ samples,
+                                                          uint32_t* __restrict__ work_counter,
+                                                          unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ptd::SceneView sv = make_scene_view<LDS_SCENE>(scn, lp, smem);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
+
+    WorkFeed feed;
+    feed_init(feed, rp);
+    bool alive = false;
+    ptd::Ray ray;
+    ray.org = ptm::mk(0, 0, 0); ray.dir = ptm::mk(0, 0, 1); ray.tnear = 0; ray.tfar = 0;
+    ptd::Trav tv;
+    tv.inv = ptm::mk(1, 1, 1);
+    tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
+    tv.cur = kDone; tv.sp = 1;
+    ptd::stack_init(stk);
+    ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
+    ptm::Pcg rng;
+    rng.state = 0; rng.inc = 1;
+    int depth = 0;
+    uint32_t my_w = 0;
+    uint32_t n_paths = 0, n_segs = 0;
+    ptd::TravStats st;
+    st.nodes = 0; st.leaves = 0;
+
+    for (;;) {
+        const bool idle = tv.cur == kDone;
+        const unsigned long long idle_mask = __ballot(idle);
+        const bool work_left = !(feed.exhausted && feed.cur >= feed.end);        // wave-uniform
+        const int n_pend = __popcll(__ballot(idle && (alive || work_left)));
+        if (n_pend >= THRESH || idle_mask == ~0ull) {
+            if (n_pend == 0) break;          // every lane idle, no live path, no work left
+            // (1) finish the segments whose traversal completed (radiance.cuh:26-75)
+            if (idle && alive) {
+                bool cont = false;
+                if (tv.best.prim < 0) {
+                    L = L + T * sv.bg;
+                } else {
+                    const ptd::Surface sf = ptd::make_surface(sv, ray, tv.best);
+                    cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                    depth++;
+                    if (depth >= rp.max_depth) cont = false;
+                }
+                if (!cont) {
+                    samples[my_w] = make_float4(L.x, L.y, L.z, 0.0f);
+                    alive = false;
+                }
+            }
+            // (2) refill dead lanes (main.cu:32-44)
+            const unsigned long long need = __ballot(idle && !alive);
+            if (need) {
+                feed_reserve(feed, rp, work_counter, lane);
+                const uint32_t avail = feed.end - feed.cur;
+                if (avail) {
+                    const uint32_t rank = lane_rank(need);
+                    const uint32_t n = (uint32_t)__popcll(need);
+                    if (idle && !alive && rank < avail) {
+                        const PathStart ps = start_path(rp, feed.region, feed.cur + rank);
+                        ray = ps.ray;
+                        rng = ps.rng;
+                        my_w = ps.sample_index;
+                        L = ptm::mk(0, 0, 0);
+                        T = ptm::mk(1, 1, 1);
+                        depth = 0;
+                        alive = true;
+                        n_paths++;
+                    }
+                    feed.cur += min(n, avail);
+                }
+            }
+            // (3) start the next traversal (scene.h:247-256)
+            if (idle && alive) {
+                ptd::trav_begin(sv, ray, tv);
+                n_segs++;
+            }
+        }
+        // ---- traversal burst
+        if (INNER < 0) {
+            // "vote" schedule: each step runs the step kind (inner-node visit or leaf test) that more lanes wait for
+#pragma unroll
+            for (int k = 0; k < -INNER; k++) {
+                const bool at_inner = tv.cur >= 0;
+                const bool at_leaf = tv.cur < 0 && tv.cur != kDone;
+                const int n_in = __popcll(__ballot(at_inner));
+                const int n_lf = __popcll(__ballot(at_leaf));
+                if (n_in >= n_lf) {
+                    if (at_inner) {
+                        if (STATS) st.nodes++;
+                        ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+                    }
+                } else if (at_leaf) {
+                    if (STATS) st.leaves++;
+                    ptd::leaf_step(sv, ray, tv, stk);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < (INNER > 0 ? INNER : 1); k++) {
+                if (tv.cur >= 0) {
+                    if (STATS) st.nodes++;
+                    ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+                }
+            }
+            if (tv.cur < 0 && tv.cur != kDone) {
+                if (STATS) st.leaves++;
+                ptd::leaf_step(sv, ray, tv, stk);
+            }
+        }
+    }
+    flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
+}
+
+// mode 0: fb = (prev + sum) * scale   (prev = accum if !first)        [final pass of pt_render]
+// mode 1: accum = prev + sum          (prev = accum if !first else 0) [intermediate pass]
+// mode 2: accum = first ? sum : accum + sum, sum started from zero    [render_progressive, main.cu:72-86]
+__global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__ samples, float* __restrict__ accum,
+                                                      float* __restrict__ fb, uint32_t npix, int spp_pass,
+                                                      int mode, int first, float scale) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    ptm::V3 sum = ptm::mk(0, 0, 0);
+    if (mode != 2 && !first) sum = ptm::mk(accum[3 * (size_t)pix], accum[3 * (size_t)pix + 1], accum[3 * (size_t)pix + 2]);
+    for (int s = 0; s < spp_pass; s++) {
+        const float4 v = samples[(size_t)s * npix + pix];
+        sum = sum + ptm::mk(v.x, v.y, v.z);                 // main.cu:47 color += radiance(...)
+    }
+    if (mode == 0) {
+        sum = sum * scale;                                  // main.cu:50 color / float(spp) == color * (1/spp)
+        fb[3 * (size_t)pix] = sum.x; fb[3 * (size_t)pix + 1] = sum.y; fb[3 * (size_t)pix + 2] = sum.z;
+    } else if (mode == 1) {
+        accum[3 * (size_t)pix] = sum.x; accum[3 * (size_t)pix + 1] = sum.y; accum[3 * (size_t)pix + 2] = sum.z;
+    } else {
+        if (!first) {
+            sum = ptm::mk(accum[3 * (size_t)pix], accum[3 * (size_t)pix + 1], accum[3 * (size_t)pix + 2]) + sum;
+        }
+        accum[3 * (size_t)pix] = sum.x; accum[3 * (size_t)pix + 1] = sum.y; accum[3 * (size_t)pix + 2] = sum.z;
+    }
+}
+
+template <bool PRUNE>
+__global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const float* __restrict__ rays, int n,
+                                                           float* __restrict__ out_tuv, int32_t* __restrict__ out_prim) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ptd::SceneView sv;
+    sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
+    sv.materials = scn.materials; sv.emission = scn.emission;
+    sv.node_stride = sizeof(DNode);
+    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
+    sv.bg = ptm::mk(0, 0, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* stk = reinterpret_cast<int32_t*>(smem) + (size_t)wave * scn.stack_cap * 64 + lane;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    ptd::Ray r;
+    r.org = ptm::mk(rays[8 * k], rays[8 * k + 1], rays[8 * k + 2]);
+    r.dir = ptm::mk(rays[8 * k + 3], rays[8 * k + 4], rays[8 * k + 5]);
+    r.tnear = rays[8 * k + 6];
+    r.tfar = rays[8 * k + 7];
+    ptd::TravStats st;
+    const ptd::Hit h = ptd::intersect<PRUNE, false>(sv, r, stk, st);
+    out_prim[k] = h.prim;
+    out_tuv[3 * k] = h.prim < 0 ? 0.0f : h.t;
+    out_tuv[3 * k + 1] = h.prim < 0 ? 0.0f : h.u;
+    out_tuv[3 * k + 2] = h.prim < 0 ? 0.0f : h.v;
+}
+
+__global__ void math_kernel(int op, const float* __restrict__ x, const float* __restrict__ y,
+                            float* __restrict__ o0, float* __restrict__ o1, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (op == 0) {
+        float s, c;
+        ptm::sincos_det(x[k], s, c);
+        o0[k] = s; o1[k] = c;
+    } else if (op == 1) {
+        o0[k] = ptm::pow_det(x[k], y[k]);
+    } else {
+        // PCG: stream = bits of x[k], seed = bits of y[k]; out0 = 1st float draw, out1 = 2nd
+        ptm::Pcg r = ptm::pcg_init((uint64_t)__builtin_bit_cast(uint32_t, x[k]), (uint64_t)__builtin_bit_cast(uint32_t, y[k]));
+        o0[k] = ptm::pcg_float(r);
+        o1[k] = ptm::pcg_float(r);
+    }
+}
+
+
+}  // namespace ptk
