@@ -64,6 +64,53 @@ def cpu_baseline(desc, params, name):
             "segments": int(cnt.segments), "bytes_per_segment_measured": round(cnt.bytes_per_segment(), 1)}
 
 
+# README.md FPS of the reference on an RTX 3080 at its UI default of 2 samples per frame, 640x480, INCLUDING per-frame CPU
+# tonemap + GL upload (README.md:10-11,112-113,121-124): the only numbers the reference publishes.
+REFERENCE_FPS = {"scene1": (65, 80), "cbox": (55, 65), "bunny": (45, 50)}
+
+
+def progressive_mode(args, hs, desc, wl):
+    """Frames/s of the interactive accumulation loop (main.cu:272-344 without the window): each frame adds SPF samples
+    per pixel into a device accumulation buffer with pt_render_accumulate; one host sync per frame, as a display would need."""
+    import torch
+
+    from pathtracer_cuda_interactive_amd.device import DeviceScene
+    spf = args.progressive
+    W, H = 640, 480
+    ds = DeviceScene(desc)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    p = hs.render_params(W, H, spf)
+    p.stream_stride = 1 << 20
+
+    def frame(k):
+        p.sample_offset = k * spf
+        ds.accumulate_into(p, acc.data_ptr(), stream)
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        frame(k)
+    t0 = time.perf_counter()
+    segs = 0
+    for k in range(args.steps):
+        frame(args.warmup + k)
+    elapsed = time.perf_counter() - t0
+    c = ds.counters()
+    fps = args.steps / elapsed
+    ref = REFERENCE_FPS.get(args.scene)
+    out = {"metric": f"progressive frames/s at {spf} samples per frame, {args.scene} 640x480 (render_progressive, main.cu:64-89)",
+           "value": round(fps, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": round(fps / (sum(ref) / 2), 1) if ref and spf == 2 else None, "dtype": "f32",
+           "data": "synthetic: scene fixture, PCG seed 1984",
+           "config": {"workload": f"{wl['label'].split(' (')[0].rsplit(' ', 2)[0]} 640x480, {spf} spp per frame, accumulate + host sync per frame",
+                      "kernel_ms_last_frame": round(c.kernel_ms, 4), "segments_last_frame": int(c.segments),
+                      "reference_fps_rtx3080_with_ui": list(ref) if ref else None,
+                      "note": "reference FPS includes its CPU tonemap + OpenGL upload per frame; this number has no display"}}
+    print(json.dumps(out), flush=True)
+    ds.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +119,9 @@ def main():
     ap.add_argument("--scene", default="cbox", choices=sorted(WORKLOADS))
     ap.add_argument("--traversal", default="exact", choices=["exact", "pruned"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--progressive", type=int, default=0, metavar="SPF",
+                    help="instead of the offline frame: time render_progressive-style frames of SPF samples each "
+                         "(pt_render_accumulate; the reference UI's default is 2, main.cu:131) and report frames/s")
     args = ap.parse_args()
 
     import torch
@@ -109,6 +159,9 @@ def main():
     spp_total = wl["spp"] * world                        # weak scaling: per-GPU paths constant
     params = hs.render_params(wl["w"], wl["h"], spp_total)
     params.traversal = PT_TRAVERSAL_PRUNED if args.traversal == "pruned" else PT_TRAVERSAL_EXACT
+
+    if args.progressive > 0:
+        return progressive_mode(args, hs, desc, wl)
 
     R = D.ShardedRenderer(desc)
     kernel_ms, resolve_ms, segs, paths = [], [], [], []
