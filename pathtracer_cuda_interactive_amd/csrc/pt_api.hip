@@ -419,6 +419,10 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         const uint64_t blocks_needed = (rd.total_work + kBlock - 1) / kBlock;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)S->num_cus * bpc, blocks_needed));
         S->info_grid = grid;
+        // chunk: 256 items per reservation for full frames; smaller for small launches (interactive 1-2 spp frames) so
+        // that the items are spread over all resident waves instead of the first total/256 of them
+        const uint64_t per_wave = rd.total_work / ((uint64_t)grid * (kBlock / 64));
+        rd.chunk = per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
 
         pt_scene::PassEvents pe{};
         HIP_TRY(hipEventCreate(&pe.t0));

@@ -19,7 +19,7 @@ using namespace ptl;
 
 
 constexpr int kBlock = 256;          // 4 waves
-constexpr uint32_t kChunk = 256;     // work items a wave reserves per atomic
+constexpr uint32_t kMaxChunk = 256;  // work items a wave reserves per atomic for big launches (RenderDev::chunk)
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -34,7 +34,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // ---- work distribution ---------------------------------------------------------------------------------------
 // The frame is cut into rp.num_regions bands of rows.  A wave first serves the band that belongs to the XCD it runs
 // on (HW_REG_XCC_ID), so the rays an XCD's L2 sees start in 1/8 of the image; when that band is exhausted it steals
-// from the next ones.  Each band has its own work counter (128 B apart); a wave reserves kChunk items per atomic.
+// from the next ones.  Each band has its own work counter (128 B apart); a wave reserves rp.chunk items per atomic
+// (256 for full frames; down to 64 for small launches so that every resident wave gets work).
 // Placement only affects speed: every work item is rendered exactly once whatever XCD picks it up.
 constexpr int kCounterStride = 32;   // uint32 slots between region counters (one 128-B line each)
 
@@ -62,11 +63,11 @@ __device__ __forceinline__ void feed_reserve(WorkFeed& f, const RenderDev& rp, u
     while (f.cur >= f.end && !f.exhausted) {
         const uint32_t total = region_rows(rp, f.region) * (uint32_t)rp.width * (uint32_t)rp.spp_pass;
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&work_counters[f.region * kCounterStride], kChunk);
+        if (lane == 0) base = atomicAdd(&work_counters[f.region * kCounterStride], rp.chunk);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base < total) {
             f.cur = base;
-            f.end = min(base + kChunk, total);
+            f.end = min(base + rp.chunk, total);
         } else if (++f.tried >= (uint32_t)rp.num_regions) {
             f.exhausted = true;
         } else {

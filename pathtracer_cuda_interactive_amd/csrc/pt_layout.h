@@ -78,6 +78,7 @@ struct RenderDev {
     uint32_t npix;                  // num_rows*width
     int32_t num_regions;            // row bands with their own work counter (XCD affinity), 1..8
     int32_t rows_per_region;        // ceil(num_rows / num_regions)
+    uint32_t chunk;                 // work items a wave reserves per atomic (64..256, multiple of 64)
 };
 
 // LDS carve-up of the trace kernel (all offsets in bytes, 16-B aligned)
