@@ -356,8 +356,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (rc) return rc;
     DeviceGuard guard;
     { int grc = guard.enter(S->device); if (grc) return grc; }
-    if ((rc = S->counters.ensure(4))) return rc;
-    HIP_TRY(hipMemsetAsync(S->counters.p, 0, 4 * sizeof(unsigned long long), stream));
+    if ((rc = S->counters.ensure(12))) return rc;
+    HIP_TRY(hipMemsetAsync(S->counters.p, 0, 12 * sizeof(unsigned long long), stream));
     S->last_stream = stream;
     S->have_timing = false;
     S->info_passes = 0;
@@ -584,6 +584,15 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "scene_bytes") *value = S->scene_bytes;
     else if (k == "num_inner_nodes") *value = S->dev.num_nodes;
     else if (k == "device") *value = S->device;
+    else if (k.rfind("diag", 0) == 0 && k.size() == 5 && k[4] >= '0' && k[4] <= '7') {
+        // schedule diagnostics of the last STATS render (trace_kernel_v2): see pt_kernels.h
+        DeviceGuard guard;
+        { int grc = guard.enter(S->device); if (grc) return grc; }
+        HIP_TRY(hipStreamSynchronize(S->last_stream));
+        unsigned long long v = 0;
+        if (S->counters.p) HIP_TRY(hipMemcpy(&v, S->counters.p + 4 + (k[4] - '0'), sizeof v, hipMemcpyDeviceToHost));
+        *value = (int64_t)v;
+    }
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
         const bool lds = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;

@@ -276,13 +276,21 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     ptd::TravStats st;
     st.nodes = 0; st.leaves = 0;
 
+    // schedule diagnostics (STATS builds only; wave-uniform, kept in scalar registers):
+    // [4] loop iterations  [5] scheduler phases  [6] lanes served by scheduler phases
+    // [7] inner steps executed  [8] lanes active in them  [9] leaf steps executed  [10] lanes active in them
+    // [11] lane-slots idle-waiting (finished traversal or empty) summed over traversal steps
+    unsigned long long dg_iter = 0, dg_sched = 0, dg_sched_lanes = 0, dg_in = 0, dg_in_lanes = 0, dg_lf = 0, dg_lf_lanes = 0, dg_wait = 0;
+
     for (;;) {
         const bool idle = tv.cur == kDone;
         const unsigned long long idle_mask = __ballot(idle);
+        if (STATS) dg_iter++;
         const bool work_left = !(feed.exhausted && feed.cur >= feed.end);        // wave-uniform
         const int n_pend = __popcll(__ballot(idle && (alive || work_left)));
         if (n_pend >= THRESH || idle_mask == ~0ull) {
             if (n_pend == 0) break;          // every lane idle, no live path, no work left
+            if (STATS) { dg_sched++; dg_sched_lanes += (unsigned)n_pend; }
             // (1) finish the segments whose traversal completed (radiance.cuh:26-75)
             if (idle && alive) {
                 bool cont = false;
@@ -336,6 +344,10 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 const bool at_leaf = tv.cur < 0 && tv.cur != kDone;
                 const int n_in = __popcll(__ballot(at_inner));
                 const int n_lf = __popcll(__ballot(at_leaf));
+                if (STATS && (n_in | n_lf)) {
+                    dg_wait += (unsigned)(64 - n_in - n_lf);
+                    if (n_in >= n_lf) { dg_in++; dg_in_lanes += (unsigned)n_in; } else { dg_lf++; dg_lf_lanes += (unsigned)n_lf; }
+                }
                 if (n_in >= n_lf) {
                     if (at_inner) {
                         if (STATS) st.nodes++;
@@ -349,10 +361,18 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
         } else {
 #pragma unroll
             for (int k = 0; k < (INNER > 0 ? INNER : 1); k++) {
+                if (STATS) {
+                    const int n_in = __popcll(__ballot(tv.cur >= 0));
+                    if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == kDone)); }
+                }
                 if (tv.cur >= 0) {
                     if (STATS) st.nodes++;
                     ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
                 }
+            }
+            if (STATS) {
+                const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != kDone));
+                if (n_lf) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == kDone)); }
             }
             if (tv.cur < 0 && tv.cur != kDone) {
                 if (STATS) st.leaves++;
@@ -361,6 +381,11 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
         }
     }
     flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
+    if (STATS && lane == 0) {
+        atomicAdd(&counters[4], dg_iter); atomicAdd(&counters[5], dg_sched); atomicAdd(&counters[6], dg_sched_lanes);
+        atomicAdd(&counters[7], dg_in); atomicAdd(&counters[8], dg_in_lanes); atomicAdd(&counters[9], dg_lf);
+        atomicAdd(&counters[10], dg_lf_lanes); atomicAdd(&counters[11], dg_wait);
+    }
 }
 
 // mode 0: fb = (prev + sum) * scale   (prev = accum if !first)        [final pass of pt_render]
