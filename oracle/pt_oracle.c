@@ -40,6 +40,7 @@ typedef struct {                                                          /* int
     int material_id, area_light_id;
 } o_isect;
 typedef pt_oracle_counters o_counters;
+#define O_TRACE(c, ch) do { if ((c)->trace && (c)->trace_len < (c)->trace_cap) (c)->trace[(c)->trace_len++] = (ch); } while (0)
 
 #define ORACLE_LIBM 0
 #define NS det
@@ -249,5 +250,22 @@ int pt_oracle_pcg(uint64_t stream, uint64_t seed, int n_draws, uint32_t* out_u32
         if (out_u32) out_u32[i] = o_pcg_next(&a);
         if (out_f32) out_f32[i] = o_pcg_float(&b);
     }
+    return PT_OK;
+}
+
+int pt_oracle_trace_pixels(const pt_scene_desc* sc, const pt_render_params* p, const int32_t* xy, int n,
+                           char* buf, uint64_t cap, uint64_t* len) {
+    int st = validate(sc, p);
+    if (st) return st;
+    if (!xy || !buf || !len) return PT_ERR_INVALID_ARG;
+    o_counters cnt;
+    memset(&cnt, 0, sizeof cnt);
+    cnt.trace = buf; cnt.trace_cap = cap;
+    const int max_depth = p->max_depth > 0 ? p->max_depth : 50, rr_depth = p->rr_depth >= 0 ? p->rr_depth : 5;
+    for (int k = 0; k < n; k++) {
+        float rgb[3];
+        render_pixel_det(sc, p, PT_ORACLE_RNG_PER_SAMPLE, xy[2 * k], xy[2 * k + 1], max_depth, rr_depth, 0, rgb, &cnt);
+    }
+    *len = cnt.trace_len;
     return PT_OK;
 }

@@ -51,6 +51,9 @@ typedef struct pt_oracle_counters {
     double   seconds;       /* wall time of the pixel loop only */
     int32_t  threads_used;
     int32_t  pad;
+    /* optional event trace (single-threaded use only): 'I' inner visit, 'L' leaf test, 'S' shaded hit, 'M' miss, 'E' path end */
+    char*    trace;
+    uint64_t trace_len, trace_cap;
 } pt_oracle_counters;
 
 /* Renders rows selected by params (same packing as pt_render) into fb (host). */
@@ -61,6 +64,11 @@ int pt_oracle_render(const pt_scene_desc* scene, const pt_render_params* params,
 int pt_oracle_render_pixels(const pt_scene_desc* scene, const pt_render_params* params,
                             const pt_oracle_opts* opts, const int32_t* xy, int n,
                             float* out_rgb, pt_oracle_counters* counters);
+
+/* Event trace of the listed pixels (x,y pairs), single-threaded: fills buf with the I/L/S/M/E events of every path in
+ * order; returns the number of bytes written in *len (truncated at cap).  For schedule simulations (tools/). */
+int pt_oracle_trace_pixels(const pt_scene_desc* scene, const pt_render_params* params, const int32_t* xy, int n,
+                           char* buf, uint64_t cap, uint64_t* len);
 
 /* Closest hit for explicit rays: n x {org[3],dir[3],tnear,tfar} -> {t,u,v}, prim (-1 miss). */
 int pt_oracle_intersect(const pt_scene_desc* scene, const float* rays, int n, int math_mode,

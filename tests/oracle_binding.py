@@ -24,10 +24,11 @@ class OracleCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("paths", "segments", "inner_pops", "leaf_tri", "leaf_sphere", "valid_hits", "closer_hits", "closer_tri",
                  "rng_draws", "emit", "term_miss", "term_rr", "term_absorb", "term_maxdepth", "max_stack",
-                 "stack_overflow")] + [("seconds", C.c_double), ("threads_used", C.c_int32), ("pad", C.c_int32)]
+                 "stack_overflow")] + [("seconds", C.c_double), ("threads_used", C.c_int32), ("pad", C.c_int32),
+                                       ("trace", C.c_void_p), ("trace_len", C.c_uint64), ("trace_cap", C.c_uint64)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+        return {n: getattr(self, n) for n, _ in self._fields_ if n not in ("pad", "trace", "trace_len", "trace_cap")}
 
     def bytes_per_segment(self):
         """Algorithmic bytes per segment of the REFERENCE layout:
@@ -68,6 +69,8 @@ def lib():
         L.pt_oracle_render_pixels.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRenderParams), C.POINTER(OracleOpts),
                                               ip, C.c_int, fp, C.POINTER(OracleCounters)]
         L.pt_oracle_intersect.argtypes = [C.POINTER(PtSceneDesc), fp, C.c_int, C.c_int, fp, ip]
+        L.pt_oracle_trace_pixels.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRenderParams), ip, C.c_int, C.c_char_p,
+                                             C.c_uint64, C.POINTER(C.c_uint64)]
         L.pt_oracle_math.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.c_int]
         L.pt_oracle_pcg.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint64)]
         _lib = L
@@ -134,3 +137,13 @@ def pcg(stream, seed, n):
     si = (C.c_uint64 * 2)()
     _chk(lib().pt_oracle_pcg(int(stream), int(seed), n, u.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(f), si), "pcg")
     return u, f, (int(si[0]), int(si[1]))
+
+
+def trace_pixels(desc, params, xy, cap=1 << 26):
+    """Event string (I inner visit, L leaf test, S shaded hit, M miss, E path end) of every path of the listed pixels."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    buf = C.create_string_buffer(cap)
+    n = C.c_uint64()
+    _chk(lib().pt_oracle_trace_pixels(C.byref(desc), C.byref(params), xy.ctypes.data_as(C.POINTER(C.c_int32)), xy.shape[0],
+                                      buf, cap, C.byref(n)), "oracle trace")
+    return buf.raw[: n.value].decode()
