@@ -67,6 +67,7 @@ struct DeviceGuard {
 };
 
 constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
+constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node table must fit in this many bytes of LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
 
 uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
@@ -79,6 +80,7 @@ struct pt_scene {
     size_t lds_per_block_max = 0;
     // scene arrays
     DevBuf<DNode> nodes;
+    DevBuf<DNode> nodes_oct;         // [8][num_nodes] octant-specialised copies (small scenes only)
     DevBuf<DPrim> prims;
     DevBuf<DNormals> normals;
     DevBuf<DMaterial> materials;
@@ -99,6 +101,7 @@ struct pt_scene {
     int64_t opt_scratch_bytes = 0;
     int64_t opt_force_global = 0;
     int64_t opt_stats = 0;
+    int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
@@ -241,6 +244,21 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     if (nodes.empty()) nodes.resize(1);   // single-primitive scene: no inner nodes; keep a dummy so pointers are valid
 
     int rc;
+    // 8 ray-octant copies of the node table for LDS-resident scenes: octant bit k set <=> 1/d[k] < 0, in which case
+    // Hit() swaps the two slab distances of axis k (bbox.cuh:40-55); here the two planes are swapped instead.
+    std::vector<DNode> nodes_oct;
+    if (nodes.size() * 8 * sizeof(DNode) <= kOctNodeLimit) {
+        nodes_oct.resize(nodes.size() * 8);
+        for (int o = 0; o < 8; o++)
+            for (size_t k = 0; k < nodes.size(); k++) {
+                DNode n = nodes[k];
+                for (int ax = 0; ax < 3; ax++)
+                    if (o & (1 << ax)) { std::swap(n.lmin[ax], n.lmax[ax]); std::swap(n.rmin[ax], n.rmax[ax]); }
+                nodes_oct[(size_t)o * nodes.size() + k] = n;
+            }
+        if ((rc = S->nodes_oct.ensure(nodes_oct.size()))) return rc;
+        HIP_TRY(hipMemcpy(S->nodes_oct.p, nodes_oct.data(), nodes_oct.size() * sizeof(DNode), hipMemcpyHostToDevice));
+    }
     if ((rc = S->nodes.ensure(nodes.size()))) return rc;
     if ((rc = S->prims.ensure(prims.size()))) return rc;
     if ((rc = S->normals.ensure(normals.size()))) return rc;
@@ -253,7 +271,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     HIP_TRY(hipMemcpy(S->emission.p, emis.data(), emis.size() * sizeof(DEmission), hipMemcpyHostToDevice));
 
     SceneDev& dv = S->dev;
-    dv.nodes = S->nodes.p; dv.prims = S->prims.p; dv.normals = S->normals.p;
+    dv.nodes = S->nodes.p; dv.nodes_oct = nodes_oct.empty() ? nullptr : S->nodes_oct.p; dv.prims = S->prims.p; dv.normals = S->normals.p;
     dv.materials = S->materials.p; dv.emission = S->emission.p;
     dv.num_nodes = (int32_t)nodes.size();
     dv.num_prims = N;
@@ -269,11 +287,13 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     return PT_OK;
 }
 
-LdsPlan make_plan(const pt_scene* S, bool lds_scene) {
+// res: 0 scene in global memory, 1 scene staged in LDS, 2 staged in LDS with the 8 octant node tables
+LdsPlan make_plan(const pt_scene* S, int res) {
     LdsPlan lp{};
     uint32_t off = 0;
-    if (lds_scene) {
-        lp.nodes_off = off; off = align16(off + (uint32_t)S->dev.num_nodes * kLdsNodeStride);
+    if (res != 0) {
+        lp.nodes_off = off;
+        off = align16(off + (uint32_t)S->dev.num_nodes * (res == 2 ? 8u * (uint32_t)sizeof(DNode) : kLdsNodeStride));
         lp.prims_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DPrim));
         lp.normals_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DNormals));
         lp.mats_off = off; off = align16(off + (uint32_t)S->dev.num_materials * sizeof(DMaterial));
@@ -296,14 +316,17 @@ TraceFn pick_kernel_v1(bool lds, bool prune, bool stats) {
     return stats ? trace_kernel<false, false, true> : trace_kernel<false, false, false>;
 }
 
+template <int RES, int THRESH, int INNER, int MINW>
+TraceFn pick_v2_r(bool prune, bool stats) {
+    if (prune) return stats ? trace_kernel_v2<RES, true, true, THRESH, INNER, MINW> : trace_kernel_v2<RES, true, false, THRESH, INNER, MINW>;
+    return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, MINW> : trace_kernel_v2<RES, false, false, THRESH, INNER, MINW>;
+}
+
 template <int THRESH, int INNER, int MINW>
-TraceFn pick_v2_ti(bool lds, bool prune, bool stats) {
-    if (lds) {
-        if (prune) return stats ? trace_kernel_v2<true, true, true, THRESH, INNER, MINW> : trace_kernel_v2<true, true, false, THRESH, INNER, MINW>;
-        return stats ? trace_kernel_v2<true, false, true, THRESH, INNER, MINW> : trace_kernel_v2<true, false, false, THRESH, INNER, MINW>;
-    }
-    if (prune) return stats ? trace_kernel_v2<false, true, true, THRESH, INNER, MINW> : trace_kernel_v2<false, true, false, THRESH, INNER, MINW>;
-    return stats ? trace_kernel_v2<false, false, true, THRESH, INNER, MINW> : trace_kernel_v2<false, false, false, THRESH, INNER, MINW>;
+TraceFn pick_v2_ti(int res, bool prune, bool stats) {
+    if (res == 2) return pick_v2_r<2, THRESH, INNER, MINW>(prune, stats);
+    if (res == 1) return pick_v2_r<1, THRESH, INNER, MINW>(prune, stats);
+    return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats);
 }
 
 // (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps.
@@ -311,24 +334,29 @@ TraceFn pick_v2_ti(bool lds, bool prune, bool stats) {
 // T40 / vote-6 / W6 (cbox 4.58 ms), scenes in global memory with T32 / I4 / W6 (bunny 11.3 ms).  I8 and unbounded
 // descent are slower, T56 starves the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained
 // 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills) is 5-8 % slower.
-TraceFn pick_kernel_v2(bool lds, bool prune, bool stats, int thresh, int inner, int minw) {
-#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(lds, prune, stats);
+TraceFn pick_kernel_v2(int res, bool prune, bool stats, int thresh, int inner, int minw) {
+#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(48, 4, 6) PT_V2(40, 4, 1) PT_V2(32, -6, 6)
 #undef PT_V2
     return nullptr;
 }
 
-TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats);
+// Residency the next launch will use (see make_plan).
+int scene_residency(const pt_scene* S) {
+    if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit) return 0;
+    if (S->opt_kernel == 2 && S->opt_octants && S->dev.nodes_oct) return 2;
+    return 1;
+}
 
-TraceFn pick_kernel(const pt_scene* S, bool lds, bool prune, bool stats) {
+TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
     if (S->opt_kernel == 2) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
-        if (t == 0) t = lds ? 40 : 32;
-        if (i == 0) i = lds ? -6 : 4;
+        if (t == 0) t = res ? 40 : 32;
+        if (i == 0) i = res ? -6 : 4;
         if (w == 0) w = 6;
-        return pick_kernel_v2(lds, prune, stats, t, i, w);
+        return pick_kernel_v2(res, prune, stats, t, i, w);
     }
-    return pick_kernel_v1(lds, prune, stats);
+    return pick_kernel_v1(res != 0, prune, stats);
 }
 
 struct RowSel {
@@ -379,10 +407,11 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
 
     const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
-    const bool lds_scene = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;
-    const LdsPlan lp = make_plan(S, lds_scene);
+    const int res = scene_residency(S);
+    const bool lds_scene = res != 0;
+    const LdsPlan lp = make_plan(S, res);
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
-    TraceFn fn = pick_kernel(S, lds_scene, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
+    TraceFn fn = pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
     if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
     if (lp.total > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
@@ -493,7 +522,7 @@ int pt_scene_destroy(pt_scene* S) {
     DeviceGuard guard;
     (void)guard.enter(S->device);
     if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
-    S->nodes.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
+    S->nodes.release(); S->nodes_oct.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
     S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->work_counter.release(); S->counters.release();
     S->drop_events();
     delete S;
@@ -563,6 +592,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "force_global") S->opt_force_global = value;
     else if (k == "stats") S->opt_stats = value;
     else if (k == "xcd_regions") S->opt_xcd_regions = value;
+    else if (k == "octants") S->opt_octants = value;
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
     else if (k == "v2_inner") S->opt_v2_inner = value;
@@ -577,6 +607,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     if (k == "grid") *value = S->info_grid;
     else if (k == "lds_bytes") *value = S->info_lds_bytes;
     else if (k == "lds_scene") *value = S->info_lds_scene;
+    else if (k == "residency") *value = scene_residency(S);
     else if (k == "passes") *value = S->info_passes;
     else if (k == "occupancy") *value = S->info_occupancy;
     else if (k == "num_cus") *value = S->num_cus;
@@ -595,8 +626,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     }
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
-        const bool lds = !S->opt_force_global && S->scene_bytes <= kLdsSceneLimit;
-        TraceFn fn = pick_kernel(S, lds, k == "vgprs_pruned", S->opt_stats != 0);
+        TraceFn fn = pick_kernel(S, scene_residency(S), k == "vgprs_pruned", S->opt_stats != 0);
         if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
         *value = fa.numRegs;

@@ -1,6 +1,6 @@
 // pt_kernels.h — the gfx950 kernels of the path tracer (included only by pt_api.hip).
 //
-//   trace_kernel_v2<LDS_SCENE,PRUNE,STATS,THRESH,INNER,MINW>   persistent wavefront path tracer with decoupled
+//   trace_kernel_v2<RES,PRUNE,STATS,THRESH,INNER,MINW>   persistent wavefront path tracer with decoupled
 //        traversal / shading scheduling (default).  Replaces render + setup_rand (main.cu:30-62) and all they call.
 //   trace_kernel<LDS_SCENE,PRUNE,STATS>   the simpler segment-synchronous schedule (option "kernel" = 1).
 //   resolve_kernel     ordered per-pixel sum of the per-sample radiances (main.cu:47,50 / 72-86).
@@ -122,11 +122,13 @@ __device__ __forceinline__ void stage_nodes_to_lds(void* dst, const DNode* src, 
 
 // The scene as this kernel instantiation sees it: staged into LDS by the whole workgroup (small scenes) or read in
 // place from global memory.  Must be called by every thread of the block (it contains a __syncthreads()).
-template <bool LDS_SCENE>
+// RES = residency of the scene: 0 global memory, 1 staged in LDS, 2 staged in LDS with 8 ray-octant node tables.
+template <int RES>
 __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, const LdsPlan& lp, unsigned char* smem) {
     ptd::SceneView sv;
-    if (LDS_SCENE) {
-        stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
+    if (RES != 0) {
+        if (RES == 2) stage_to_lds(smem + lp.nodes_off, scn.nodes_oct, 8u * (uint32_t)scn.num_nodes * sizeof(DNode));
+        else stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
         stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
         stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
         stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
@@ -137,11 +139,13 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
         sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
         sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
         sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
-        sv.node_stride = kLdsNodeStride;
+        sv.node_stride = RES == 2 ? (uint32_t)sizeof(DNode) : kLdsNodeStride;
+        sv.oct_stride = RES == 2 ? (uint32_t)scn.num_nodes * (uint32_t)sizeof(DNode) : 0u;
     } else {
         sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
         sv.materials = scn.materials; sv.emission = scn.emission;
         sv.node_stride = sizeof(DNode);
+        sv.oct_stride = 0;
     }
     sv.num_emission = scn.num_emission;
     sv.root_ref = scn.root_ref;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
                                                        uint32_t* __restrict__ work_counter,
                                                        unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ptd::SceneView sv = make_scene_view<LDS_SCENE>(scn, lp, smem);
+    const ptd::SceneView sv = make_scene_view<(LDS_SCENE ? 1 : 0)>(scn, lp, smem);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -245,13 +249,13 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 // scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
 // (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
 // the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
-template <bool LDS_SCENE, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW>
+template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
                                                           uint32_t* __restrict__ work_counter,
                                                           unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const ptd::SceneView sv = make_scene_view<LDS_SCENE>(scn, lp, smem);
+    const ptd::SceneView sv = make_scene_view<RES>(scn, lp, smem);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     ptd::Trav tv;
     tv.inv = ptm::mk(1, 1, 1);
     tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
-    tv.cur = kDone; tv.sp = 1;
+    tv.cur = kDone; tv.sp = 1; tv.node_off = 0;
     ptd::stack_init(stk);
     ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
     ptm::Pcg rng;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 if (n_in >= n_lf) {
                     if (at_inner) {
                         if (STATS) st.nodes++;
-                        ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+                        ptd::inner_step<PRUNE, RES == 2>(sv, ray.org, tv, stk);
                     }
                 } else if (at_leaf) {
                     if (STATS) st.leaves++;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 }
                 if (tv.cur >= 0) {
                     if (STATS) st.nodes++;
-                    ptd::inner_step<PRUNE>(sv, ray.org, tv, stk);
+                    ptd::inner_step<PRUNE, RES == 2>(sv, ray.org, tv, stk);
                 }
             }
             if (STATS) {

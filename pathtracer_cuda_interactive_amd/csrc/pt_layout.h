@@ -55,6 +55,7 @@ struct alignas(16) DEmission {      // 16 B: scene.lights[id] as radiance.cuh:36
 
 struct SceneDev {
     const DNode* nodes;
+    const DNode* nodes_oct;         // 8 octant-specialised copies [8][num_nodes] (small scenes only), else nullptr
     const DPrim* prims;
     const DNormals* normals;
     const DMaterial* materials;

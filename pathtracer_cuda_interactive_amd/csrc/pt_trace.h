@@ -41,7 +41,8 @@ struct TravStats {
 // space is a compile-time property of each kernel instantiation).
 struct SceneView {
     const DNode* nodes;
-    uint32_t node_stride;   // bytes between consecutive nodes: 64 in global memory, 80 in LDS (bank spreading)
+    uint32_t node_stride;   // bytes between consecutive nodes (64)
+    uint32_t oct_stride;    // bytes between the 8 ray-octant copies of the node table; 0 = one table (see inner_step)
     const DPrim* prims;
     const DNormals* normals;
     const DMaterial* materials;
@@ -60,6 +61,7 @@ struct Trav {
     Hit best;          // closest hit so far (scene.h:248-249,270-273)
     int32_t cur;       // node reference being visited; kDone = traversal finished
     int32_t sp;        // entries on this lane's LDS stack column
+    uint32_t node_off; // byte offset of the node table this ray reads (octant copy), 0 when there is one table
 };
 
 // `stk` (this lane's column of the wave's LDS stack, entry k at stk[k*64]) must hold kDone in entry 0: stack_init().
@@ -70,33 +72,47 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
     t.best.t = FLT_MAX; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = -1;
     t.cur = sv.root_ref;           // scene.h:256: the root is pushed without a box test
     t.sp = 1;                      // entry 0 is the kDone sentinel
+    // octant = which of the swaps of bbox.cuh:40-55 apply to this ray (inv < 0 per axis)
+    const uint32_t oct = (t.inv.x < 0.0f ? 1u : 0u) | (t.inv.y < 0.0f ? 2u : 0u) | (t.inv.z < 0.0f ? 4u : 0u);
+    t.node_off = oct * sv.oct_stride;
 }
 
 // One inner-node visit (requires t.cur >= 0): test both child boxes, descend into the nearer one,
 // push the farther one (scene.h:278-297).  PRUNE=false visits exactly the nodes the reference visits;
 // PRUNE=true also skips a child whose box entry lies beyond the closest hit.
-template <bool PRUNE>
+// OCT=true: the node table exists in 8 copies, one per ray octant, in which every box is stored as (near planes,
+// far planes) for that octant — the swaps of bbox.cuh:40-55 are done once at scene-build time instead of with 12
+// selects per visit.  Same arithmetic on the same operands, so the result is bit-identical.
+template <bool PRUNE, bool OCT>
 __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, int32_t* stk) {
-    const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (uint32_t)t.cur * sv.node_stride;
-    const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x
-    const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy
-    const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz
+    const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (OCT ? t.node_off : 0u) + (uint32_t)t.cur * sv.node_stride;
+    const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x      (OCT: lnear.xyz lfar.x)
+    const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy     (OCT: lfar.yz  rnear.xy)
+    const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz    (OCT: rnear.z  rfar.xyz)
     const float4 d = ld4(nd, 3);    // left right - -
     const V3 inv = t.inv;
-    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-    // bbox.cuh:36-55 for the left box
-    float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
-    float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
-    float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
-    float ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
-    float ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
+    float ltn, ltf, rtn, rtf;
+    if (OCT) {
+        ltn = fmax2(fmax2((a.x - o.x) * inv.x, (a.y - o.y) * inv.y), (a.z - o.z) * inv.z);
+        ltf = fmin2(fmin2((a.w - o.x) * inv.x, (b.x - o.y) * inv.y), (b.y - o.z) * inv.z);
+        rtn = fmax2(fmax2((b.z - o.x) * inv.x, (b.w - o.y) * inv.y), (c.x - o.z) * inv.z);
+        rtf = fmin2(fmin2((c.y - o.x) * inv.x, (c.z - o.y) * inv.y), (c.w - o.z) * inv.z);
+    } else {
+        const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+        // bbox.cuh:36-55 for the left box
+        float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
+        float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
+        float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
+        ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
+        ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
+        // right box
+        float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
+        float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
+        float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
+        rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
+        rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
+    }
     bool hl = ltf >= fmax2(0.0f, ltn);
-    // right box
-    float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
-    float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
-    float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
-    float rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
-    float rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
     bool hr = rtf >= fmax2(0.0f, rtn);
     if (PRUNE) {
         // Skip a child whose box entry lies beyond the closest hit.  The 1e-5 relative slack keeps boxes whose
@@ -198,7 +214,7 @@ __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, in
     while (t.cur != kDone) {
         while (t.cur >= 0) {                    // descend through inner nodes until this lane holds a leaf
             if (STATS) st.nodes++;
-            inner_step<PRUNE>(sv, ray.org, t, stk);
+            inner_step<PRUNE, false>(sv, ray.org, t, stk);
         }
         if (t.cur != kDone) {                   // one primitive test, then pop
             if (STATS) st.leaves++;

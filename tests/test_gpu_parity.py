@@ -115,6 +115,26 @@ def test_random_scenes_all_materials(oracle, seed):
         ds.close()
 
 
+@pytest.mark.parametrize("name", ["cbox", "scene1", "scene1_phong", "tetrahedron"])
+def test_octant_node_tables_do_not_change_the_image(oracle, dscenes, name):
+    """Small scenes keep 8 ray-octant copies of the node table in LDS (near/far planes pre-swapped, no per-visit
+    selects).  Same arithmetic on the same operands: the frame must not change by a bit."""
+    hs, d = load_scene(name)
+    ds = dscenes(name)
+    p = hs.render_params(70, 50, 6, seed=21)
+    want, _ = oracle.render(d, p)
+    assert ds.info("residency") == 2
+    with_oct = ds.render(p)
+    ds.set_option("octants", 0)
+    try:
+        assert ds.info("residency") == 1
+        without = ds.render(p)
+    finally:
+        ds.set_option("octants", 1)
+    assert_bit_equal(with_oct, want, name + " octants")
+    assert_bit_equal(without, want, name + " single table")
+
+
 def test_row_ranges_and_strides_tile_the_image(oracle, dscenes):
     hs, d = load_scene("cbox")
     ds = dscenes("cbox")
