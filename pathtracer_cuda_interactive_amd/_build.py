@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(REPO_DIR, "include")
 
 HOST_LIB = os.path.join(PKG_DIR, "libpt_host.so")
-HIP_LIB = os.path.join(PKG_DIR, "libpt_hip.so")
+HIP_LIB = os.environ.get("PT_HIP_LIB", os.path.join(PKG_DIR, "libpt_hip.so"))   # override: A/B builds in tools/
 
 HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off"]
 HIP_FLAGS = [

@@ -293,7 +293,7 @@ LdsPlan make_plan(const pt_scene* S, int res) {
     uint32_t off = 0;
     if (res != 0) {
         lp.nodes_off = off;
-        off = align16(off + (uint32_t)S->dev.num_nodes * (res == 2 ? 8u * (uint32_t)sizeof(DNode) : kLdsNodeStride));
+        off = align16(off + (uint32_t)S->dev.num_nodes * (res == 2 ? 8u : 1u) * kLdsNodeStride);
         lp.prims_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DPrim));
         lp.normals_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DNormals));
         lp.mats_off = off; off = align16(off + (uint32_t)S->dev.num_materials * sizeof(DMaterial));

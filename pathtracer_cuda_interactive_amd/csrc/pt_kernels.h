@@ -110,10 +110,12 @@ __device__ __forceinline__ void stage_to_lds(void* dst, const void* src, uint32_
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
 }
 
-// Node placement in LDS.  An 80-B stride (16 bank positions instead of 4 for ds_read_b128) was measured on cbox:
-// no gain within run-to-run noise (5.02 vs 4.90 ms, tools/gpu_tune.py round 3) although 41 % of LDS cycles are
-// bank conflicts — the kernel is VALU-issue bound, not LDS bound — so nodes stay densely packed.
-constexpr uint32_t kLdsNodeStride = 64;
+// Node placement in LDS: kLdsNodeStride bytes between consecutive nodes of a table.  64 = densely packed (4 bank
+// positions for ds_read_b128), 80 = 16 bank positions.  Set by -DPT_LDS_NODE_STRIDE for experiments.
+#ifndef PT_LDS_NODE_STRIDE
+#define PT_LDS_NODE_STRIDE 64
+#endif
+constexpr uint32_t kLdsNodeStride = PT_LDS_NODE_STRIDE;
 __device__ __forceinline__ void stage_nodes_to_lds(void* dst, const DNode* src, uint32_t n) {
     const float4* s = reinterpret_cast<const float4*>(src);
     for (uint32_t i = threadIdx.x; i < n * 4; i += blockDim.x)
@@ -127,7 +129,7 @@ template <int RES>
 __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, const LdsPlan& lp, unsigned char* smem) {
     ptd::SceneView sv;
     if (RES != 0) {
-        if (RES == 2) stage_to_lds(smem + lp.nodes_off, scn.nodes_oct, 8u * (uint32_t)scn.num_nodes * sizeof(DNode));
+        if (RES == 2) stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes_oct, 8u * (uint32_t)scn.num_nodes);
         else stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
         stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
         stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
@@ -139,8 +141,8 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
         sv.normals = reinterpret_cast<const DNormals*>(smem + lp.normals_off);
         sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
         sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
-        sv.node_stride = RES == 2 ? (uint32_t)sizeof(DNode) : kLdsNodeStride;
-        sv.oct_stride = RES == 2 ? (uint32_t)scn.num_nodes * (uint32_t)sizeof(DNode) : 0u;
+        sv.node_stride = kLdsNodeStride;
+        sv.oct_stride = RES == 2 ? (uint32_t)scn.num_nodes * kLdsNodeStride : 0u;
     } else {
         sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
         sv.materials = scn.materials; sv.emission = scn.emission;
