@@ -288,7 +288,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
 }
 
 // res: 0 scene in global memory, 1 scene staged in LDS, 2 staged in LDS with the 8 octant node tables
-LdsPlan make_plan(const pt_scene* S, int res) {
+LdsPlan make_plan(const pt_scene* S, int res, bool stack16) {
     LdsPlan lp{};
     uint32_t off = 0;
     if (res != 0) {
@@ -300,8 +300,8 @@ LdsPlan make_plan(const pt_scene* S, int res) {
         lp.emis_off = off; off = align16(off + (uint32_t)std::max(S->dev.num_emission, 1) * sizeof(DEmission));
     }
     lp.stack_off = off;
-    off += (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
-    lp.total = off;
+    off += (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * (stack16 ? 2u : 4u);
+    lp.total = align16(off);
     return lp;
 }
 
@@ -409,7 +409,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
     const int res = scene_residency(S);
     const bool lds_scene = res != 0;
-    const LdsPlan lp = make_plan(S, res);
+    const LdsPlan lp = make_plan(S, res, res != 0 && S->opt_kernel == 2);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
     TraceFn fn = pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
     if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pt_layout.h"
 #include "pt_math.h"
 #include "pt_trace.h"
@@ -259,9 +261,12 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ptd::SceneView sv = make_scene_view<RES>(scn, lp, smem);
 
+    // LDS-resident scenes are small enough for 16-bit node / primitive references on the stack
+    using STK = typename std::conditional<RES != 0, int16_t, int32_t>::type;
+    constexpr int32_t DONE = ptd::done_value<STK>();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    int32_t* stk = reinterpret_cast<int32_t*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
+    STK* stk = reinterpret_cast<STK*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
 
     WorkFeed feed;
     feed_init(feed, rp);
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     ptd::Trav tv;
     tv.inv = ptm::mk(1, 1, 1);
     tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
-    tv.cur = kDone; tv.sp = 1; tv.node_off = 0;
+    tv.cur = DONE; tv.sp = 1; tv.node_off = 0;
     ptd::stack_init(stk);
     ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
     ptm::Pcg rng;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     unsigned long long dg_iter = 0, dg_sched = 0, dg_sched_lanes = 0, dg_in = 0, dg_in_lanes = 0, dg_lf = 0, dg_lf_lanes = 0, dg_wait = 0;
 
     for (;;) {
-        const bool idle = tv.cur == kDone;
+        const bool idle = tv.cur == DONE;
         const unsigned long long idle_mask = __ballot(idle);
         if (STATS) dg_iter++;
         const bool work_left = !(feed.exhausted && feed.cur >= feed.end);        // wave-uniform
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
 #pragma unroll
             for (int k = 0; k < -INNER; k++) {
                 const bool at_inner = tv.cur >= 0;
-                const bool at_leaf = tv.cur < 0 && tv.cur != kDone;
+                const bool at_leaf = tv.cur < 0 && tv.cur != DONE;
                 const int n_in = __popcll(__ballot(at_inner));
                 const int n_lf = __popcll(__ballot(at_leaf));
                 if (STATS && (n_in | n_lf)) {
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 if (n_in >= n_lf) {
                     if (at_inner) {
                         if (STATS) st.nodes++;
-                        ptd::inner_step<PRUNE, RES == 2>(sv, ray.org, tv, stk);
+                        ptd::inner_step<PRUNE, RES == 2, STK>(sv, ray.org, tv, stk);
                     }
                 } else if (at_leaf) {
                     if (STATS) st.leaves++;
@@ -369,18 +374,18 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             for (int k = 0; k < (INNER > 0 ? INNER : 1); k++) {
                 if (STATS) {
                     const int n_in = __popcll(__ballot(tv.cur >= 0));
-                    if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == kDone)); }
+                    if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
                 }
                 if (tv.cur >= 0) {
                     if (STATS) st.nodes++;
-                    ptd::inner_step<PRUNE, RES == 2>(sv, ray.org, tv, stk);
+                    ptd::inner_step<PRUNE, RES == 2, STK>(sv, ray.org, tv, stk);
                 }
             }
             if (STATS) {
-                const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != kDone));
-                if (n_lf) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == kDone)); }
+                const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != DONE));
+                if (n_lf) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
             }
-            if (tv.cur < 0 && tv.cur != kDone) {
+            if (tv.cur < 0 && tv.cur != DONE) {
                 if (STATS) st.leaves++;
                 ptd::leaf_step(sv, ray, tv, stk);
             }

@@ -64,8 +64,12 @@ struct Trav {
     uint32_t node_off; // byte offset of the node table this ray reads (octant copy), 0 when there is one table
 };
 
-// `stk` (this lane's column of the wave's LDS stack, entry k at stk[k*64]) must hold kDone in entry 0: stack_init().
-__device__ __forceinline__ void stack_init(int32_t* stk) { stk[0] = kDone; }
+// The traversal stack lives in LDS, one column per lane (entry k at stk[k*64]).  Its element type STK is int32_t, or
+// int16_t for LDS-resident scenes (node and primitive counts far below 32767) to halve the LDS footprint.  The value
+// that means "traversal finished" must be representable in STK: done_value<STK>().
+template <class STK> __device__ __forceinline__ constexpr int32_t done_value() { return sizeof(STK) == 2 ? -32768 : kDone; }
+// Entry 0 of the column holds the done value, so popping an empty stack ends the traversal without an emptiness test.
+template <class STK> __device__ __forceinline__ void stack_init(STK* stk) { stk[0] = (STK)done_value<STK>(); }
 
 __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, Trav& t) {
     t.inv = mk(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
@@ -83,8 +87,8 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
 // OCT=true: the node table exists in 8 copies, one per ray octant, in which every box is stored as (near planes,
 // far planes) for that octant — the swaps of bbox.cuh:40-55 are done once at scene-build time instead of with 12
 // selects per visit.  Same arithmetic on the same operands, so the result is bit-identical.
-template <bool PRUNE, bool OCT>
-__device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, int32_t* stk) {
+template <bool PRUNE, bool OCT, class STK>
+__device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, STK* stk) {
     const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (OCT ? t.node_off : 0u) + (uint32_t)t.cur * sv.node_stride;
     const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x      (OCT: lnear.xyz lfar.x)
     const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy     (OCT: lfar.yz  rnear.xy)
@@ -131,7 +135,7 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
     const bool both = hl && hr;
     const int32_t next = (hl && (!hr || left_first)) ? L : R;
     if (both) {
-        stk[t.sp * 64] = left_first ? R : L;
+        stk[t.sp * 64] = (STK)(left_first ? R : L);
         t.sp++;
     }
     if (hl || hr) {
@@ -142,8 +146,9 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
     }
 }
 
-// One leaf visit (requires t.cur < 0 && t.cur != kDone): primitive test, keep the hit if strictly closer, pop.
-__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, int32_t* stk) {
+// One leaf visit (requires t.cur < 0 && t.cur != done_value<STK>()): primitive test, keep the hit if strictly closer, pop.
+template <class STK>
+__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk) {
     const int32_t prim = ~t.cur;
     const DPrim* pr = sv.prims + prim;
     const float4 a = ld4(pr, 0);
@@ -214,7 +219,7 @@ __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, in
     while (t.cur != kDone) {
         while (t.cur >= 0) {                    // descend through inner nodes until this lane holds a leaf
             if (STATS) st.nodes++;
-            inner_step<PRUNE, false>(sv, ray.org, t, stk);
+            inner_step<PRUNE, false, int32_t>(sv, ray.org, t, stk);
         }
         if (t.cur != kDone) {                   // one primitive test, then pop
             if (STATS) st.leaves++;
