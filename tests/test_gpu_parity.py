@@ -135,6 +135,31 @@ def test_octant_node_tables_do_not_change_the_image(oracle, dscenes, name):
     assert_bit_equal(without, want, name + " single table")
 
 
+@pytest.mark.parametrize("n_tris,n_spheres", [(30, 3), (44, 2), (46, 1), (47, 1), (60, 4), (170, 4), (186, 2), (196, 4), (400, 4)])
+def test_residency_thresholds(oracle, n_tris, n_spheres):
+    """Scenes around the two size thresholds: 8 octant node tables in LDS (<= 48 inner nodes), one table in LDS
+    (<= 36 KB of scene), global memory.  Every residency must render the oracle's image."""
+    hs = random_scene(100 + n_tris, n_tris=n_tris, n_spheres=n_spheres)
+    d = hs.finalize()
+    p = hs.render_params(48, 36, 4, seed=n_tris)
+    want, _ = oracle.render(d, p)
+    ds = dev.DeviceScene(d)
+    try:
+        res = ds.info("residency")
+        inner = ds.info("num_inner_nodes")
+        expect = 2 if inner * 8 * 64 <= 24 * 1024 else (1 if ds.info("scene_bytes") <= 36 * 1024 else 0)
+        assert res == expect, (res, inner, ds.info("scene_bytes"))
+        assert_bit_equal(ds.render(p), want, f"{n_tris} tris residency {res}")
+        if res == 2:
+            ds.set_option("octants", 0)
+            assert_bit_equal(ds.render(p), want, f"{n_tris} tris residency 1")
+        ds.set_option("force_global", 1)
+        assert ds.info("residency") == 0
+        assert_bit_equal(ds.render(p), want, f"{n_tris} tris residency 0")
+    finally:
+        ds.close()
+
+
 def test_row_ranges_and_strides_tile_the_image(oracle, dscenes):
     hs, d = load_scene("cbox")
     ds = dscenes("cbox")
