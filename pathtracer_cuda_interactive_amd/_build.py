@@ -18,7 +18,7 @@ INCLUDE = os.path.join(REPO_DIR, "include")
 HOST_LIB = os.path.join(PKG_DIR, "libpt_host.so")
 HIP_LIB = os.environ.get("PT_HIP_LIB", os.path.join(PKG_DIR, "libpt_hip.so"))   # override: A/B builds in tools/
 
-HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off"]
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", "-pthread"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
     "-ffp-contract=off",                      # no FMA contraction: bit-parity with the oracle

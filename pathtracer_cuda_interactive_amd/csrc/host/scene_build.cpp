@@ -1,7 +1,9 @@
 // Scene flattening + BVH build: the host producer of the hot path's inputs.
 // Follows Scene::Scene (scene.cpp:11-153) and construct_bvh (bvh.cu:16-54).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <future>
 #include <limits>
 
 #include "parsed_scene.h"
@@ -53,9 +55,10 @@ struct BoxId {
 
 struct BvhBuilder {
     std::vector<BoxId>& boxes;
-    std::vector<pt_bvh_node>& pool;
+    std::vector<pt_bvh_node>& pool;     // pre-sized to 2N-1; a subtree with n leaves owns 2n-1 consecutive slots (post-order)
     int sort_mode;
-    int max_depth = 0;
+    std::atomic<int> max_depth{0};
+    std::atomic<int> tasks_in_flight{0};
 
     static float center(const BoxId& b, int axis) {   // bvh.cu:5-6: (p_max + p_min) / 2.0f
         switch (axis) {
@@ -65,18 +68,27 @@ struct BvhBuilder {
         }
     }
 
-    // bvh.cu:16-54, on the sub-range [lo,hi) in place (the reference copies the range and sorts the copy:
-    // same input sequence, same result).
-    int build(size_t lo, size_t hi, int depth) {
-        if (depth > max_depth) max_depth = depth;
-        if (hi - lo == 1) {
+    void note_depth(int depth) {
+        int cur = max_depth.load(std::memory_order_relaxed);
+        while (depth > cur && !max_depth.compare_exchange_weak(cur, depth, std::memory_order_relaxed)) {}
+    }
+
+    // bvh.cu:16-54 on the sub-range [lo,hi) in place (the reference copies the range and sorts the copy: same input
+    // sequence, same result).  The node pool is post-order exactly like the reference's push_back order: the subtree
+    // of [lo,hi) fills pool[base, base + 2(hi-lo)-1) with its root last, so independent subtrees can be built by
+    // different threads and still land at the reference's indices.  Returns the index of the subtree's root.
+    int build(size_t lo, size_t hi, int depth, size_t base) {
+        note_depth(depth);
+        const size_t n = hi - lo;
+        const size_t self = base + 2 * n - 2;
+        if (n == 1) {
             pt_bvh_node node;
             node.left = node.right = -1;
             node.prim = boxes[lo].id;
             std::memcpy(node.bmin, &boxes[lo].lo, 12);
             std::memcpy(node.bmax, &boxes[lo].hi, 12);
-            pool.push_back(node);
-            return int(pool.size()) - 1;
+            pool[self] = node;
+            return int(self);
         }
         const float inf = std::numeric_limits<float>::infinity();
         f3 bmin{inf, inf, inf}, bmax{-inf, -inf, -inf};           // bbox.cuh:19-26
@@ -97,15 +109,28 @@ struct BvhBuilder {
                 return a.id < b.id;
             });
         }
-        size_t mid = lo + (hi - lo) / 2;
+        const size_t mid = lo + n / 2;
+        const size_t left_base = base, right_base = base + 2 * (mid - lo) - 1;
+        int left_id, right_id;
+        // big subtrees: build the left half on another thread (bounded number of tasks)
+        if (n > 32768 && tasks_in_flight.load(std::memory_order_relaxed) < 16) {
+            tasks_in_flight.fetch_add(1, std::memory_order_relaxed);
+            auto fut = std::async(std::launch::async, [&, lo, mid, depth, left_base] { return build(lo, mid, depth + 1, left_base); });
+            right_id = build(mid, hi, depth + 1, right_base);
+            left_id = fut.get();
+            tasks_in_flight.fetch_sub(1, std::memory_order_relaxed);
+        } else {
+            left_id = build(lo, mid, depth + 1, left_base);
+            right_id = build(mid, hi, depth + 1, right_base);
+        }
         pt_bvh_node node;
         std::memcpy(node.bmin, &bmin, 12);
         std::memcpy(node.bmax, &bmax, 12);
-        node.left = build(lo, mid, depth + 1);
-        node.right = build(mid, hi, depth + 1);
+        node.left = left_id;
+        node.right = right_id;
         node.prim = -1;
-        pool.push_back(node);
-        return int(pool.size()) - 1;
+        pool[self] = node;
+        return int(self);
     }
 };
 
@@ -211,10 +236,10 @@ void HostScene::finalize(int sort_mode) {
             boxes[i] = {lo, hi, i};
         }
     }
-    nodes.reserve(2 * boxes.size());
+    nodes.assign(2 * boxes.size() - 1, pt_bvh_node{});
     BvhBuilder b{boxes, nodes, sort_mode};
-    root = b.build(0, boxes.size(), 1);
-    depth = b.max_depth;               // computeMaxDepth (bvh.cu:56-65): leaves count 1
+    root = b.build(0, boxes.size(), 1, 0);
+    depth = b.max_depth.load();        // computeMaxDepth (bvh.cu:56-65): leaves count 1
     finalized = true;
 }
 

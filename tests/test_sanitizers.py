@@ -15,7 +15,7 @@ def test_host_pipeline_and_oracle_are_clean_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off",
            f'-DREPO="{REPO}"', f'-DTMP="{tmp_path}"', "-I", os.path.join(REPO, "include"), "-I", os.path.join(REPO, "oracle"),
            os.path.join(REPO, "tests", "sanitize", "driver.cpp")] + srcs + ["-x", "c", os.path.join(REPO, "oracle", "pt_oracle.c"),
-           "-lm", "-lpthread", "-o", exe]
+           "-lm", "-lpthread", "-pthread", "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
