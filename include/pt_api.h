@@ -179,8 +179,17 @@ int pt_render_accumulate(pt_scene* scene, const pt_render_params* p, float* accu
 
 int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the scene's last stream */
 
-/* Tuning knobs (all optional): blocks per CU of the persistent kernel (0=auto),
- * scratch cap in bytes for per-sample radiance (0=auto), kernel variant. */
+/* Tuning knobs (all optional; none of them changes a bit of the rendered image):
+ *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel
+ *   "v2_thresh" / "v2_inner" / "v2_minw"   scheduler variant of kernel 2; 0 = automatic (by scene residency)
+ *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
+ *   "xcd_regions"   0 (default) 8 row bands with XCD affinity, 1 = a single work queue
+ *   "force_global"  1 = never stage the scene in LDS
+ *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query)
+ *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 1 GiB); larger jobs run in sample passes
+ *   "stats"         1 = also count node visits / leaf tests (pt_counters) and schedule diagnostics ("diag0".."diag7")
+ * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables),
+ * "passes", "occupancy", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned". */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
 int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
 
