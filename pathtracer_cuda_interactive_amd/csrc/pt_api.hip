@@ -87,6 +87,7 @@ struct pt_scene {
     DevBuf<DEmission> emission;
     SceneDev dev{};
     uint32_t scene_bytes = 0;
+    bool tri_only = false;           // the scene holds no sphere
     int bvh_depth = 0;
     // scratch
     DevBuf<float4> samples;
@@ -101,6 +102,7 @@ struct pt_scene {
     int64_t opt_scratch_bytes = 0;
     int64_t opt_force_global = 0;
     int64_t opt_stats = 0;
+    int64_t opt_specialize = 1;      // compile-time specialisation on scene content (no spheres -> sphere code removed)
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
@@ -169,6 +171,10 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             return fail(PT_ERR_BAD_SCENE, "unknown shape type");
         }
     }
+
+    S->tri_only = true;
+    for (int i = 0; i < N; i++)
+        if (d->shapes[i].type == PT_SHAPE_SPHERE) { S->tri_only = false; break; }
 
     // ---- BVH: reference node pool -> inner-only nodes carrying both child boxes
     std::vector<int32_t> inner_id(d->num_nodes, -1);
@@ -316,17 +322,22 @@ TraceFn pick_kernel_v1(bool lds, bool prune, bool stats) {
     return stats ? trace_kernel<false, false, true> : trace_kernel<false, false, false>;
 }
 
+template <int RES, int THRESH, int INNER, int MINW, bool TRI>
+TraceFn pick_v2_rt(bool prune, bool stats) {
+    if (prune) return stats ? trace_kernel_v2<RES, true, true, THRESH, INNER, MINW, TRI> : trace_kernel_v2<RES, true, false, THRESH, INNER, MINW, TRI>;
+    return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, MINW, TRI> : trace_kernel_v2<RES, false, false, THRESH, INNER, MINW, TRI>;
+}
+
 template <int RES, int THRESH, int INNER, int MINW>
-TraceFn pick_v2_r(bool prune, bool stats) {
-    if (prune) return stats ? trace_kernel_v2<RES, true, true, THRESH, INNER, MINW> : trace_kernel_v2<RES, true, false, THRESH, INNER, MINW>;
-    return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, MINW> : trace_kernel_v2<RES, false, false, THRESH, INNER, MINW>;
+TraceFn pick_v2_r(bool prune, bool stats, bool tri_only) {
+    return tri_only ? pick_v2_rt<RES, THRESH, INNER, MINW, true>(prune, stats) : pick_v2_rt<RES, THRESH, INNER, MINW, false>(prune, stats);
 }
 
 template <int THRESH, int INNER, int MINW>
-TraceFn pick_v2_ti(int res, bool prune, bool stats) {
-    if (res == 2) return pick_v2_r<2, THRESH, INNER, MINW>(prune, stats);
-    if (res == 1) return pick_v2_r<1, THRESH, INNER, MINW>(prune, stats);
-    return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats);
+TraceFn pick_v2_ti(int res, bool prune, bool stats, bool tri_only) {
+    if (res == 2) return pick_v2_r<2, THRESH, INNER, MINW>(prune, stats, tri_only);
+    if (res == 1) return pick_v2_r<1, THRESH, INNER, MINW>(prune, stats, tri_only);
+    return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats, tri_only);
 }
 
 // (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps.
@@ -334,9 +345,9 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats) {
 // T40 / vote-6 / W6 (cbox 4.58 ms), scenes in global memory with T32 / I4 / W6 (bunny 11.3 ms).  I8 and unbounded
 // descent are slower, T56 starves the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained
 // 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills) is 5-8 % slower.
-TraceFn pick_kernel_v2(int res, bool prune, bool stats, int thresh, int inner, int minw) {
-#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats);
-    PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(48, 4, 6) PT_V2(40, 4, 1) PT_V2(32, -6, 6)
+TraceFn pick_kernel_v2(int res, bool prune, bool stats, bool tri_only, int thresh, int inner, int minw) {
+#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, tri_only);
+    PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6)
 #undef PT_V2
     return nullptr;
 }
@@ -352,9 +363,10 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
     if (S->opt_kernel == 2) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
         if (t == 0) t = res ? 40 : 32;
-        if (i == 0) i = res ? -6 : 4;
+        const bool tri = S->tri_only && S->opt_specialize;
+        if (i == 0) i = (res && !tri) ? -6 : 4;     // vote burst only pays when leaf tests are a mix of spheres and triangles
         if (w == 0) w = 6;
-        return pick_kernel_v2(res, prune, stats, t, i, w);
+        return pick_kernel_v2(res, prune, stats, S->tri_only && S->opt_specialize, t, i, w);
     }
     return pick_kernel_v1(res != 0, prune, stats);
 }
@@ -593,6 +605,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "stats") S->opt_stats = value;
     else if (k == "xcd_regions") S->opt_xcd_regions = value;
     else if (k == "octants") S->opt_octants = value;
+    else if (k == "specialize") S->opt_specialize = value;
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
     else if (k == "v2_inner") S->opt_v2_inner = value;

@@ -1,6 +1,6 @@
 // pt_kernels.h — the gfx950 kernels of the path tracer (included only by pt_api.hip).
 //
-//   trace_kernel_v2<RES,PRUNE,STATS,THRESH,INNER,MINW>   persistent wavefront path tracer with decoupled
+//   trace_kernel_v2<RES,PRUNE,STATS,THRESH,INNER,MINW,TRI_ONLY>   persistent wavefront path tracer with decoupled
 //        traversal / shading scheduling (default).  Replaces render + setup_rand (main.cu:30-62) and all they call.
 //   trace_kernel<LDS_SCENE,PRUNE,STATS>   the simpler segment-synchronous schedule (option "kernel" = 1).
 //   resolve_kernel     ordered per-pixel sum of the per-sample radiances (main.cu:47,50 / 72-86).
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
             if (h.prim < 0) {
                 L = L + T * sv.bg;                          // radiance.cuh:27-30
             } else {
-                const ptd::Surface sf = ptd::make_surface(sv, ray, h);
+                const ptd::Surface sf = ptd::make_surface<false>(sv, ray, h);
                 cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
                 depth++;
                 if (depth >= rp.max_depth) cont = false;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 // scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
 // (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
 // the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
-template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW>
+template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, bool TRI_ONLY>
 __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
                                                           uint32_t* __restrict__ work_counter,
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 if (tv.best.prim < 0) {
                     L = L + T * sv.bg;
                 } else {
-                    const ptd::Surface sf = ptd::make_surface(sv, ray, tv.best);
+                    const ptd::Surface sf = ptd::make_surface<TRI_ONLY>(sv, ray, tv.best);
                     cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
                     depth++;
                     if (depth >= rp.max_depth) cont = false;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                     }
                 } else if (at_leaf) {
                     if (STATS) st.leaves++;
-                    ptd::leaf_step(sv, ray, tv, stk);
+                    ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
                 }
             }
         } else {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             }
             if (tv.cur < 0 && tv.cur != DONE) {
                 if (STATS) st.leaves++;
-                ptd::leaf_step(sv, ray, tv, stk);
+                ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
             }
         }
     }

@@ -147,7 +147,8 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
 }
 
 // One leaf visit (requires t.cur < 0 && t.cur != done_value<STK>()): primitive test, keep the hit if strictly closer, pop.
-template <class STK>
+// TRI_ONLY: the scene holds no sphere, the sphere branch is compiled out.
+template <class STK, bool TRI_ONLY>
 __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk) {
     const int32_t prim = ~t.cur;
     const DPrim* pr = sv.prims + prim;
@@ -156,7 +157,7 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
     const float4 c = ld4(pr, 2);
     const V3 o = ray.org;
     const int32_t info = __builtin_bit_cast(int32_t, c.y);
-    if (info >= 0) {
+    if (TRI_ONLY || info >= 0) {
         // Möller–Trumbore, shape.cuh:188-215
         const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
         const V3 e1 = p1 - p0;
@@ -223,7 +224,7 @@ __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, in
         }
         if (t.cur != kDone) {                   // one primitive test, then pop
             if (STATS) st.leaves++;
-            leaf_step(sv, ray, t, stk);
+            leaf_step<int32_t, false>(sv, ray, t, stk);
         }
     }
     return t.best;
@@ -235,6 +236,7 @@ struct Surface {
     int32_t material, light;
 };
 
+template <bool TRI_ONLY>
 __device__ __forceinline__ Surface make_surface(const SceneView& sv, const Ray& ray, const Hit& h) {
     Surface s;
     const DPrim* pr = sv.prims + h.prim;
@@ -244,7 +246,7 @@ __device__ __forceinline__ Surface make_surface(const SceneView& sv, const Ray& 
     const int32_t info = __builtin_bit_cast(int32_t, c.y);
     s.material = info & 0x7fffffff;
     s.light = __builtin_bit_cast(int32_t, c.z);
-    if (info >= 0) {
+    if (TRI_ONLY || info >= 0) {
         const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
         const float w = 1.0f - h.u - h.v;
         s.p = p0 * w + p1 * h.u + p2 * h.v;
