@@ -88,6 +88,7 @@ struct pt_scene {
     SceneDev dev{};
     uint32_t scene_bytes = 0;
     bool tri_only = false;           // the scene holds no sphere
+    bool diffuse_only = false;       // every material is DIFFUSE
     int bvh_depth = 0;
     // scratch
     DevBuf<float4> samples;
@@ -172,6 +173,9 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         }
     }
 
+    S->diffuse_only = true;
+    for (int m = 0; m < d->num_materials; m++)
+        if (d->materials[m].type != PT_MAT_DIFFUSE) { S->diffuse_only = false; break; }
     S->tri_only = true;
     for (int i = 0; i < N; i++)
         if (d->shapes[i].type == PT_SHAPE_SPHERE) { S->tri_only = false; break; }
@@ -322,22 +326,24 @@ TraceFn pick_kernel_v1(bool lds, bool prune, bool stats) {
     return stats ? trace_kernel<false, false, true> : trace_kernel<false, false, false>;
 }
 
-template <int RES, int THRESH, int INNER, int MINW, bool TRI>
+template <int RES, int THRESH, int INNER, int MINW, int SPEC>
 TraceFn pick_v2_rt(bool prune, bool stats) {
-    if (prune) return stats ? trace_kernel_v2<RES, true, true, THRESH, INNER, MINW, TRI> : trace_kernel_v2<RES, true, false, THRESH, INNER, MINW, TRI>;
-    return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, MINW, TRI> : trace_kernel_v2<RES, false, false, THRESH, INNER, MINW, TRI>;
+    if (prune) return stats ? trace_kernel_v2<RES, true, true, THRESH, INNER, MINW, SPEC> : trace_kernel_v2<RES, true, false, THRESH, INNER, MINW, SPEC>;
+    return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, MINW, SPEC> : trace_kernel_v2<RES, false, false, THRESH, INNER, MINW, SPEC>;
 }
 
 template <int RES, int THRESH, int INNER, int MINW>
-TraceFn pick_v2_r(bool prune, bool stats, bool tri_only) {
-    return tri_only ? pick_v2_rt<RES, THRESH, INNER, MINW, true>(prune, stats) : pick_v2_rt<RES, THRESH, INNER, MINW, false>(prune, stats);
+TraceFn pick_v2_r(bool prune, bool stats, int spec) {
+    if (spec == 2) return pick_v2_rt<RES, THRESH, INNER, MINW, 2>(prune, stats);
+    if (spec == 1) return pick_v2_rt<RES, THRESH, INNER, MINW, 1>(prune, stats);
+    return pick_v2_rt<RES, THRESH, INNER, MINW, 0>(prune, stats);
 }
 
 template <int THRESH, int INNER, int MINW>
-TraceFn pick_v2_ti(int res, bool prune, bool stats, bool tri_only) {
-    if (res == 2) return pick_v2_r<2, THRESH, INNER, MINW>(prune, stats, tri_only);
-    if (res == 1) return pick_v2_r<1, THRESH, INNER, MINW>(prune, stats, tri_only);
-    return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats, tri_only);
+TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
+    if (res == 2) return pick_v2_r<2, THRESH, INNER, MINW>(prune, stats, spec);
+    if (res == 1) return pick_v2_r<1, THRESH, INNER, MINW>(prune, stats, spec);
+    return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats, spec);
 }
 
 // (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps.
@@ -345,8 +351,8 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, bool tri_only) {
 // T40 / vote-6 / W6 (cbox 4.58 ms), scenes in global memory with T32 / I4 / W6 (bunny 11.3 ms).  I8 and unbounded
 // descent are slower, T56 starves the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained
 // 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills) is 5-8 % slower.
-TraceFn pick_kernel_v2(int res, bool prune, bool stats, bool tri_only, int thresh, int inner, int minw) {
-#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, tri_only);
+TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
+#define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6)
 #undef PT_V2
     return nullptr;
@@ -366,7 +372,8 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
         const bool tri = S->tri_only && S->opt_specialize;
         if (i == 0) i = (res && !tri) ? -6 : 4;     // vote burst only pays when leaf tests are a mix of spheres and triangles
         if (w == 0) w = 6;
-        return pick_kernel_v2(res, prune, stats, S->tri_only && S->opt_specialize, t, i, w);
+        const int spec = !tri ? 0 : (S->diffuse_only ? 2 : 1);
+        return pick_kernel_v2(res, prune, stats, spec, t, i, w);
     }
     return pick_kernel_v1(res != 0, prune, stats);
 }

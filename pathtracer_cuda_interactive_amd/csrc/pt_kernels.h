@@ -1,6 +1,6 @@
 // pt_kernels.h — the gfx950 kernels of the path tracer (included only by pt_api.hip).
 //
-//   trace_kernel_v2<RES,PRUNE,STATS,THRESH,INNER,MINW,TRI_ONLY>   persistent wavefront path tracer with decoupled
+//   trace_kernel_v2<RES,PRUNE,STATS,THRESH,INNER,MINW,SPEC>   persistent wavefront path tracer with decoupled
 //        traversal / shading scheduling (default).  Replaces render + setup_rand (main.cu:30-62) and all they call.
 //   trace_kernel<LDS_SCENE,PRUNE,STATS>   the simpler segment-synchronous schedule (option "kernel" = 1).
 //   resolve_kernel     ordered per-pixel sum of the per-sample radiances (main.cu:47,50 / 72-86).
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
                 L = L + T * sv.bg;                          // radiance.cuh:27-30
             } else {
                 const ptd::Surface sf = ptd::make_surface<false>(sv, ray, h);
-                cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                cont = ptd::shade_and_bounce<false>(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
                 depth++;
                 if (depth >= rp.max_depth) cont = false;
             }
@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 // scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
 // (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
 // the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
-template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, bool TRI_ONLY>
+// SPEC = specialisation on scene content: 0 generic, 1 no spheres, 2 no spheres and only diffuse materials.
+template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, int SPEC>
 __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
                                                           uint32_t* __restrict__ work_counter,
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     const ptd::SceneView sv = make_scene_view<RES>(scn, lp, smem);
 
     // LDS-resident scenes are small enough for 16-bit node / primitive references on the stack
+    constexpr bool TRI_ONLY = SPEC >= 1, DIFFUSE_ONLY = SPEC >= 2;
     using STK = typename std::conditional<RES != 0, int16_t, int32_t>::type;
     constexpr int32_t DONE = ptd::done_value<STK>();
     const int lane = threadIdx.x & 63;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                     L = L + T * sv.bg;
                 } else {
                     const ptd::Surface sf = ptd::make_surface<TRI_ONLY>(sv, ray, tv.best);
-                    cont = ptd::shade_and_bounce(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                    cont = ptd::shade_and_bounce<DIFFUSE_ONLY>(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
                     depth++;
                     if (depth >= rp.max_depth) cont = false;
                 }

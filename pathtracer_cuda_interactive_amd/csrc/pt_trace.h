@@ -308,6 +308,9 @@ __device__ __forceinline__ V3 sample_cos_n_hemisphere(float ux, float uy, float 
 
 // One bounce of radiance() after a hit (radiance.cuh:32-74): emission, BSDF sampling,
 // throughput update, next ray, Russian roulette.  Returns false when the path ends.
+// DIFFUSE_ONLY: every material of the scene is DIFFUSE; the mirror / plastic / Phong code (and the registers its fp64
+// pow needs) is compiled out.
+template <bool DIFFUSE_ONLY>
 __device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surface& sf, Ray& ray, Pcg& rng,
                                                  V3& L, V3& T, int depth, int rr_depth) {
     V3 n = sf.n;
@@ -326,7 +329,7 @@ __device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surf
     const int32_t mtype = __builtin_bit_cast(int32_t, m0.x);
     const V3 refl = mk(m0.y, m0.z, m0.w);
     V3 wo;
-    if (mtype == 0) {                                   // DIFFUSE: scene.h:429-433 + 370-375
+    if (DIFFUSE_ONLY || mtype == 0) {                   // DIFFUSE: scene.h:429-433 + 370-375
         const float ux = pcg_float(rng);
         const float uy = pcg_float(rng);
         wo = to_world_about(n, sample_cos_hemisphere(ux, uy));
