@@ -25,6 +25,9 @@ HIP_FLAGS = [
     "-fno-gpu-flush-denormals-to-zero",       # keep fp32 denormals (x86 does)
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    # SLP vectorisation turns the scalar fp32 vector math into v_pk_add/mul_f32 plus ~20 v_mov shuffles per leaf test;
+    # packed fp32 issues at half rate on gfx950, so the packing only adds instructions: cbox 4.21 -> 3.78 ms without it
+    "-fno-slp-vectorize",
 ]
 
 

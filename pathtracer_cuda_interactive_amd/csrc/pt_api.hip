@@ -437,7 +437,9 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(fn), kBlock, lp.total));
     if (occ < 1) occ = 1;
-    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : occ;
+    // scenes read from global memory run best with at most 5 blocks per CU (more resident rays thrash L1/L2:
+    // bunny 10.9 ms at 5, 11.4 ms at 7; tools/gpu_occ_test.py); LDS-resident scenes take every block they can get
+    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (res == 0 ? std::min(occ, 5) : occ);
     S->info_occupancy = occ;
     S->info_lds_bytes = lp.total;
     S->info_lds_scene = lds_scene;
