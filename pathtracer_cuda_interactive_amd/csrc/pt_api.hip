@@ -69,6 +69,8 @@ struct DeviceGuard {
 constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
 constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node table must fit in this many bytes of LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
+constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band counters, one 128-B line each
+constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
 
 uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
@@ -94,8 +96,10 @@ struct pt_scene {
     DevBuf<float4> samples;
     DevBuf<float> accum;
     DevBuf<float> fb_tmp;
-    DevBuf<uint32_t> work_counter;
-    DevBuf<unsigned long long> counters;
+    // control block: [0, kWorkBytes) the band work counters, then the statistics (kNumCounters uint64, pt_kernels.h)
+    DevBuf<unsigned long long> ctl;
+    uint32_t* work_counter() const { return reinterpret_cast<uint32_t*>(ctl.p); }
+    unsigned long long* counters() const { return ctl.p ? ctl.p + kWorkWords : nullptr; }
     hipStream_t last_stream = nullptr;
     bool have_timing = false;
     // options
@@ -111,11 +115,17 @@ struct pt_scene {
     // info of last launch
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
-    std::vector<PassEvents> pass_events;
+    std::vector<PassEvents> pass_events;                         // pool, reused from frame to frame
+    size_t passes_timed = 0;                                     // events of the last frame: pass_events[0 .. passes_timed)
     void drop_events() {
         for (auto& pe : pass_events) { (void)hipEventDestroy(pe.t0); (void)hipEventDestroy(pe.t1); (void)hipEventDestroy(pe.r1); }
         pass_events.clear();
+        passes_timed = 0;
     }
+    // launch configuration of the last kernel variant used (occupancy query and attribute call are not free per frame)
+    const void* cfg_fn = nullptr;
+    uint32_t cfg_lds = 0;
+    int cfg_occ = 0;
 };
 
 namespace {
@@ -378,6 +388,16 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
     return pick_kernel_v1(res != 0, prune, stats);
 }
 
+// Sums the kCounterSlots per-workgroup counter slots of the last frame (the caller has synchronised the stream).
+int read_slot_sums(const pt_scene* S, unsigned long long* out) {
+    std::vector<unsigned long long> raw(kTimelineBase);
+    HIP_TRY(hipMemcpy(raw.data(), S->counters(), raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::fill(out, out + kSlotStride, 0ull);
+    for (int s = 0; s < kCounterSlots; s++)
+        for (int k = 0; k < kSlotStride; k++) out[k] += raw[(size_t)s * kSlotStride + k];
+    return PT_OK;
+}
+
 struct RowSel {
     int begin, step, count;
 };
@@ -403,12 +423,13 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (rc) return rc;
     DeviceGuard guard;
     { int grc = guard.enter(S->device); if (grc) return grc; }
-    if ((rc = S->counters.ensure(12))) return rc;
-    HIP_TRY(hipMemsetAsync(S->counters.p, 0, 12 * sizeof(unsigned long long), stream));
+    if ((rc = S->ctl.ensure(kWorkWords + kNumCounters))) return rc;
+    // one memset per frame: work counters + the 64 counter slots (+ timeline / histograms when a STATS kernel will run)
+    HIP_TRY(hipMemsetAsync(S->ctl.p, 0, (kWorkWords + (S->opt_stats ? kNumCounters : kTimelineBase)) * sizeof(unsigned long long), stream));
     S->last_stream = stream;
     S->have_timing = false;
     S->info_passes = 0;
-    S->drop_events();
+    S->passes_timed = 0;
     if (rows.count == 0) return PT_OK;
 
     const uint64_t npix = (uint64_t)rows.count * (uint64_t)p->width;
@@ -422,7 +443,6 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (mode == 2 && n_pass > 1)
         return fail(PT_ERR_UNSUPPORTED, "pt_render_accumulate: spp of one call must fit the scratch budget (single pass)");
     if (n_pass > 1 && (rc = S->accum.ensure(npix * 3))) return rc;
-    if ((rc = S->work_counter.ensure(8 * kCounterStride))) return rc;
 
     const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
@@ -432,11 +452,14 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
     TraceFn fn = pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
     if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
-    if (lp.total > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
-    int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(fn), kBlock, lp.total));
-    if (occ < 1) occ = 1;
+    if (S->cfg_fn != reinterpret_cast<const void*>(fn) || S->cfg_lds != lp.total) {
+        if (lp.total > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
+        int q = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(fn), kBlock, lp.total));
+        S->cfg_fn = reinterpret_cast<const void*>(fn); S->cfg_lds = lp.total; S->cfg_occ = std::max(q, 1);
+    }
+    const int occ = S->cfg_occ;
     // scenes read from global memory run best with at most 5 blocks per CU (more resident rays thrash L1/L2:
     // bunny 10.9 ms at 5, 11.4 ms at 7; tools/gpu_occ_test.py); LDS-resident scenes take every block they can get
     int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (res == 0 ? std::min(occ, 5) : occ);
@@ -474,15 +497,18 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         const uint64_t per_wave = rd.total_work / ((uint64_t)grid * (kBlock / 64));
         rd.chunk = per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
 
-        pt_scene::PassEvents pe{};
-        HIP_TRY(hipEventCreate(&pe.t0));
-        HIP_TRY(hipEventCreate(&pe.t1));
-        HIP_TRY(hipEventCreate(&pe.r1));
-        S->pass_events.push_back(pe);
-        HIP_TRY(hipMemsetAsync(S->work_counter.p, 0, 8 * kCounterStride * sizeof(uint32_t), stream));
+        if (S->pass_events.size() <= (size_t)pass) {
+            pt_scene::PassEvents fresh{};
+            HIP_TRY(hipEventCreate(&fresh.t0));
+            HIP_TRY(hipEventCreate(&fresh.t1));
+            HIP_TRY(hipEventCreate(&fresh.r1));
+            S->pass_events.push_back(fresh);
+        }
+        const pt_scene::PassEvents pe = S->pass_events[pass];
+        if (pass > 0) HIP_TRY(hipMemsetAsync(S->ctl.p, 0, kWorkBytes, stream));
         HIP_TRY(hipEventRecord(pe.t0, stream));
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
-                           S->work_counter.p, S->counters.p);
+                           S->work_counter(), S->counters());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(pe.t1, stream));
 
@@ -504,6 +530,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(pe.r1, stream));
         S->info_passes++;
+        S->passes_timed = (size_t)pass + 1;
     }
     S->have_timing = true;
     return PT_OK;
@@ -544,7 +571,7 @@ int pt_scene_destroy(pt_scene* S) {
     (void)guard.enter(S->device);
     if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
     S->nodes.release(); S->nodes_oct.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
-    S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->work_counter.release(); S->counters.release();
+    S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->ctl.release();
     S->drop_events();
     delete S;
     return PT_OK;
@@ -586,13 +613,15 @@ int pt_get_counters(pt_scene* S, pt_counters* out) {
     DeviceGuard guard;
     { int grc = guard.enter(S->device); if (grc) return grc; }
     HIP_TRY(hipStreamSynchronize(S->last_stream));
-    if (!S->counters.p) return PT_OK;
-    unsigned long long c[4];
-    HIP_TRY(hipMemcpy(c, S->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    if (!S->ctl.p) return PT_OK;
+    unsigned long long c[kSlotStride];
+    int rc = read_slot_sums(S, c);
+    if (rc) return rc;
     out->paths = c[0]; out->segments = c[1]; out->node_visits = c[2]; out->leaf_tests = c[3];
     if (S->have_timing) {
         double t = 0, r = 0;
-        for (auto& pe : S->pass_events) {
+        for (size_t k = 0; k < S->passes_timed; k++) {
+            const pt_scene::PassEvents& pe = S->pass_events[k];
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, pe.t0, pe.t1));
             t += ms;
@@ -637,13 +666,22 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "scene_bytes") *value = S->scene_bytes;
     else if (k == "num_inner_nodes") *value = S->dev.num_nodes;
     else if (k == "device") *value = S->device;
-    else if (k.rfind("diag", 0) == 0 && k.size() == 5 && k[4] >= '0' && k[4] <= '7') {
-        // schedule diagnostics of the last STATS render (trace_kernel_v2): see pt_kernels.h
+    else if (k.rfind("diag", 0) == 0 && k.size() >= 5 && k.size() <= 7 && k.find_first_not_of("0123456789", 4) == std::string::npos &&
+             std::stoi(k.substr(4)) < 8 + kNumCounters - kTimelineBase) {
+        // schedule diagnostics / launch timeline of the last STATS render (trace_kernel_v2): see pt_kernels.h
         DeviceGuard guard;
         { int grc = guard.enter(S->device); if (grc) return grc; }
         HIP_TRY(hipStreamSynchronize(S->last_stream));
         unsigned long long v = 0;
-        if (S->counters.p) HIP_TRY(hipMemcpy(&v, S->counters.p + 4 + (k[4] - '0'), sizeof v, hipMemcpyDeviceToHost));
+        const int idx = std::stoi(k.substr(4));
+        if (S->ctl.p && idx < 8) {                  // schedule diagnostics: summed over the counter slots
+            unsigned long long c[kSlotStride];
+            int rc = read_slot_sums(S, c);
+            if (rc) return rc;
+            v = c[4 + idx];
+        } else if (S->ctl.p) {                      // launch timeline / histograms
+            HIP_TRY(hipMemcpy(&v, S->counters() + kTimelineBase + (idx - 8), sizeof v, hipMemcpyDeviceToHost));
+        }
         *value = (int64_t)v;
     }
     else if (k == "vgprs" || k == "vgprs_pruned") {

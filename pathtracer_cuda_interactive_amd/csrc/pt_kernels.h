@@ -64,12 +64,13 @@ __device__ __forceinline__ void feed_init(WorkFeed& f, const RenderDev& rp) {
 __device__ __forceinline__ void feed_reserve(WorkFeed& f, const RenderDev& rp, uint32_t* work_counters, int lane) {
     while (f.cur >= f.end && !f.exhausted) {
         const uint32_t total = region_rows(rp, f.region) * (uint32_t)rp.width * (uint32_t)rp.spp_pass;
+        const uint32_t chunk = rp.chunk;
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&work_counters[f.region * kCounterStride], rp.chunk);
+        if (lane == 0) base = atomicAdd(&work_counters[f.region * kCounterStride], chunk);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base < total) {
             f.cur = base;
-            f.end = min(base + rp.chunk, total);
+            f.end = min(base + chunk, total);
         } else if (++f.tried >= (uint32_t)rp.num_regions) {
             f.exhausted = true;
         } else {
@@ -157,16 +158,30 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
     return sv;
 }
 
-// pt_counters: per-wave sums, one atomic per wave and counter.
+// pt_counters: per-wave sums, one atomic per wave and counter.  Same-address atomics serialise in L2 (~5 ns each:
+// 12 k of them at the end of a 6144-wave launch were ~60 us of every frame), so the sums are spread over kCounterSlots
+// slots of one 128-B line each, picked by workgroup id; the host adds the slots up (pt_get_counters).
+// Slot layout (uint64): [0] paths [1] segments [2] node visits [3] leaf tests [4..11] schedule diagnostics.
+// After the slots: launch timeline [kTimelineBase + 0..7] and two 128-bin histograms (STATS builds only).
+constexpr int kCounterSlots = 64;
+constexpr int kSlotStride = 16;
+constexpr int kTimelineBase = kCounterSlots * kSlotStride;
+constexpr int kNumCounters = kTimelineBase + 8 + 2 * 128;
+
+__device__ __forceinline__ unsigned long long* counter_slot(unsigned long long* counters) {
+    return counters + (blockIdx.x % kCounterSlots) * kSlotStride;
+}
+
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(unsigned long long* counters, int lane, uint32_t n_paths, uint32_t n_segs,
                                                const ptd::TravStats& st) {
     const unsigned long long a = wave_sum(n_paths), b = wave_sum(n_segs);
     const unsigned long long c = STATS ? wave_sum(st.nodes) : 0ull, d = STATS ? wave_sum(st.leaves) : 0ull;
     if (lane == 0) {
-        atomicAdd(&counters[0], a);
-        atomicAdd(&counters[1], b);
-        if (STATS) { atomicAdd(&counters[2], c); atomicAdd(&counters[3], d); }
+        unsigned long long* slot = counter_slot(counters);
+        atomicAdd(&slot[0], a);
+        atomicAdd(&slot[1], b);
+        if (STATS) { atomicAdd(&slot[2], c); atomicAdd(&slot[3], d); }
     }
 }
 
@@ -260,7 +275,12 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                                                           uint32_t* __restrict__ work_counter,
                                                           unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // launch timeline (STATS builds only): 100 MHz constant clock at entry, after staging, when the wave first finds the
+    // work feed dry, at exit — reduced over waves into counters[kTimelineBase..] (see flush below)
+    const unsigned long long tl_entry = STATS ? wall_clock64() : 0ull;
     const ptd::SceneView sv = make_scene_view<RES>(scn, lp, smem);
+    const unsigned long long tl_staged = STATS ? wall_clock64() : 0ull;
+    unsigned long long tl_dry = 0;
 
     // LDS-resident scenes are small enough for 16-bit node / primitive references on the stack
     constexpr bool TRI_ONLY = SPEC >= 1, DIFFUSE_ONLY = SPEC >= 2;
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     // schedule diagnostics (STATS builds only; wave-uniform, kept in scalar registers):
     // [4] loop iterations  [5] scheduler phases  [6] lanes served by scheduler phases
     // [7] inner steps executed  [8] lanes active in them  [9] leaf steps executed  [10] lanes active in them
-    // [11] lane-slots idle-waiting (finished traversal or empty) summed over traversal steps
+    // [11] lane-slots idle-waiting (finished traversal or empty) summed over traversal steps (per counter slot)
     unsigned long long dg_iter = 0, dg_sched = 0, dg_sched_lanes = 0, dg_in = 0, dg_in_lanes = 0, dg_lf = 0, dg_lf_lanes = 0, dg_wait = 0;
 
     for (;;) {
@@ -300,8 +320,14 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
         const unsigned long long idle_mask = __ballot(idle);
         if (STATS) dg_iter++;
         const bool work_left = !(feed.exhausted && feed.cur >= feed.end);        // wave-uniform
+        if (STATS && !work_left && tl_dry == 0) tl_dry = wall_clock64();
         const int n_pend = __popcll(__ballot(idle && (alive || work_left)));
-        if (n_pend >= THRESH || idle_mask == ~0ull) {
+        // drain (no work left to refill with): fewer than THRESH lanes may be alive at all.  Scenes in global memory serve
+        // the finished segments as soon as a quarter of the live lanes wait instead of waiting for the slowest traversal
+        // (bunny: -1 % at 64 spp, -15 % for 2-spp frames); LDS-resident scenes gain nothing from it and keep the plain rule
+        int thresh = THRESH;
+        if (RES == 0 && !work_left) thresh = min(THRESH, max(1, (__popcll(__ballot(alive)) + 3) / 4));
+        if (n_pend >= thresh || idle_mask == ~0ull) {
             if (n_pend == 0) break;          // every lane idle, no live path, no work left
             if (STATS) { dg_sched++; dg_sched_lanes += (unsigned)n_pend; }
             // (1) finish the segments whose traversal completed (radiance.cuh:26-75)
@@ -395,9 +421,21 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     }
     flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
     if (STATS && lane == 0) {
-        atomicAdd(&counters[4], dg_iter); atomicAdd(&counters[5], dg_sched); atomicAdd(&counters[6], dg_sched_lanes);
-        atomicAdd(&counters[7], dg_in); atomicAdd(&counters[8], dg_in_lanes); atomicAdd(&counters[9], dg_lf);
-        atomicAdd(&counters[10], dg_lf_lanes); atomicAdd(&counters[11], dg_wait);
+        const unsigned long long tl_exit = wall_clock64();
+        unsigned long long* slot = counter_slot(counters);
+        atomicAdd(&slot[4], dg_iter); atomicAdd(&slot[5], dg_sched); atomicAdd(&slot[6], dg_sched_lanes);
+        atomicAdd(&slot[7], dg_in); atomicAdd(&slot[8], dg_in_lanes); atomicAdd(&slot[9], dg_lf);
+        atomicAdd(&slot[10], dg_lf_lanes); atomicAdd(&slot[11], dg_wait);
+        // timeline, in 10-ns ticks: [0] ~(earliest entry)  [1] latest staged  [2] ~(earliest dry)  [3] latest dry
+        // [4] latest exit  [5] sum over waves of (exit - dry)  [6] sum of (dry - staged)  [7] waves
+        unsigned long long* tl = counters + kTimelineBase;
+        if (tl_dry == 0) tl_dry = tl_exit;
+        atomicMax(&tl[0], ~tl_entry); atomicMax(&tl[1], tl_staged); atomicMax(&tl[2], ~tl_dry);
+        atomicMax(&tl[3], tl_dry); atomicMax(&tl[4], tl_exit); atomicAdd(&tl[5], tl_exit - tl_dry);
+        atomicAdd(&tl[6], tl_dry - tl_staged); atomicAdd(&tl[7], 1ull);
+        // histograms over waves, 100-us bins after the wave's own entry: [8..135] feed found dry, [136..263] exit
+        atomicAdd(&tl[8 + min(127ull, (tl_dry - tl_entry) / 10000ull)], 1ull);
+        atomicAdd(&tl[136 + min(127ull, (tl_exit - tl_entry) / 10000ull)], 1ull);
     }
 }
 
