@@ -36,7 +36,8 @@ def worker(scenes):
         for _ in range(8 if spp else 6):
             ds.render(full)
             ts.append(ds.counters().kernel_ms)
-        out[spec] = {"parity": ok, "median_ms": float(np.median(ts[1:])), "min_ms": float(min(ts[1:])), "vgprs": ds.info("vgprs")}
+        out[spec] = {"parity": ok, "median_ms": float(np.median(ts[1:])), "min_ms": float(min(ts[1:])), "vgprs": ds.info("vgprs"),
+                     "occ": ds.info("occupancy"), "grid": ds.info("grid"), "lds": ds.info("lds_bytes")}
         ds.close()
     print("AB_RESULT " + json.dumps(out), flush=True)
 
@@ -62,7 +63,7 @@ def main():
         for label, _ in libs:
             rs = [r[s] for r in res[label] if s in r]
             if rs:
-                print(f"{s:15s} {label:18s} parity={'OK ' if all(r['parity'] for r in rs) else 'BAD'} vgpr={rs[0]['vgprs']:3d} "
+                print(f"{s:15s} {label:18s} parity={'OK ' if all(r['parity'] for r in rs) else 'BAD'} vgpr={rs[0]['vgprs']:3d} occ={rs[0]['occ']} grid={rs[0]['grid']} lds={rs[0]['lds']} "
                       f"median {np.median([r['median_ms'] for r in rs]):9.3f} ms  min {min(r['min_ms'] for r in rs):9.3f} ms", flush=True)
 
 
