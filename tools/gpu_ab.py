@@ -1,7 +1,7 @@
 """A/B timing of differently-built libpt_hip.so files on the GPU box (build experiments that are compile-time switches).
 Each build runs in its own child process (PT_HIP_LIB selects the library), builds alternate A B A B to cancel drift,
 and every child first checks bit-exact parity against the oracle on a small frame.
-Usage: python tools/gpu_ab.py label=path/to/lib.so [label=path ...] -- scene[@spp] [scene[@spp] ...]"""
+Usage: python tools/gpu_ab.py label=path/to/lib.so[:option=value,...] [label=path ...] -- scene[@spp] [scene[@spp] ...]"""
 import json
 import os
 import subprocess
@@ -27,6 +27,9 @@ def worker(scenes):
         hs = standins.BUILDERS[name](sc) if name in standins.BUILDERS else HostScene.load(os.path.join(sc, name + ".pts"))
         d = hs.finalize(PT_BVH_SORT_REFERENCE)
         ds = dev.DeviceScene(d)
+        for kv in filter(None, os.environ.get("PT_AB_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            ds.set_option(k, int(v))
         small = hs.render_params(48, 32, 2, seed=5)
         want, _ = ob.render(d, small)
         ok = bool((ds.render(small).view(np.uint32) == want.view(np.uint32)).all())
@@ -46,12 +49,18 @@ def main():
     if sys.argv[1] == "--worker":
         return worker(sys.argv[2:])
     cut = sys.argv.index("--")
-    libs = [a.split("=", 1) for a in sys.argv[1:cut]]
+    libs = []
+    opts = {}
+    for a in sys.argv[1:cut]:
+        label, rest = a.split("=", 1)
+        path, _, o = rest.partition(":")
+        libs.append((label, path))
+        opts[label] = o
     scenes = sys.argv[cut + 1:]
     res = {label: [] for label, _ in libs}
     for rnd in range(2):
         for label, path in libs:
-            env = dict(os.environ, PT_HIP_LIB=os.path.abspath(path))
+            env = dict(os.environ, PT_HIP_LIB=os.path.abspath(path), PT_AB_OPTIONS=opts[label])
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"] + scenes, env=env, capture_output=True, text=True, timeout=900)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("AB_RESULT ")]
             if not line:

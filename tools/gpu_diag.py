@@ -12,6 +12,8 @@ for name in ("cbox", "bunny"):
     hs = HostScene.load(os.path.join(REPO, "tests", "golden", "scenes", name + ".pts"))
     ds = dev.DeviceScene(hs.finalize(PT_BVH_SORT_REFERENCE))
     ds.set_option("stats", 1)
+    for kv in filter(None, os.environ.get("PT_AB_OPTIONS", "").split(",")):
+        ds.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for spp in spps:
         p = hs.render_params(640, 480, spp)
         p.max_depth = max_depth
