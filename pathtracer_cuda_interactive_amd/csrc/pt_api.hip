@@ -356,15 +356,17 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
     return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats, spec);
 }
 
-// (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps.
+// (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps, 1..9 a
+// burst of `inner` inner steps + 1 leaf step, >= 100 the encoded burst REPS*100 + N_INNER*10 + N_LEAF (pt_kernels.h).
 // Measured on MI355X (tools/gpu_tune.py, tools/gpu_ab.py, profiles/r01_tune_round*.log): LDS-resident scenes with
-// spheres are fastest with T40 / vote-6 / W6, triangle-only LDS scenes with T40 / I3 / W6 (cbox 3.99 ms against 4.10 with
-// I4, 4.20 with I2), scenes in global memory with T32 / I4 / W6 (bunny 10.7 ms).  I8 and unbounded descent are slower,
-// T56 starves the scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %,
-// W8 (64 VGPRs, spills) is 5-8 % slower.
+// spheres are fastest with T40 / vote-6 / W6, triangle-only LDS scenes with T40 / 6 inner + 2 leaf steps / W6 (cbox 3.77 ms
+// against 3.99 with 3+1, 4.10 with 4+1, 3.92 with two rounds of 3+1; r01_tune_round21/22), scenes in global memory with
+// T32 / I4 / W6 (bunny 10.7 ms; every other burst shape within 1 %).  I8 and unbounded descent are slower, T56 starves the
+// scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills)
+// is 5-8 % slower.
 TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
-    PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6)
+    PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
 #undef PT_V2
     return nullptr;
 }
@@ -381,7 +383,7 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
         if (t == 0) t = res ? 40 : 32;
         const bool tri = S->tri_only && S->opt_specialize;
-        if (i == 0) i = (res && !tri) ? -6 : (res ? 3 : 4);   // vote burst only pays when leaf tests are a mix of spheres and triangles
+        if (i == 0) i = (res && !tri) ? -6 : (res ? 162 : 4);   // vote burst only pays when leaf tests are a mix of spheres and triangles
         if (w == 0) w = 6;
         const int spec = !tri ? 0 : (S->diffuse_only ? 2 : 1);
         return pick_kernel_v2(res, prune, stats, spec, t, i, w);

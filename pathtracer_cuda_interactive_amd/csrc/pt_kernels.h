@@ -398,24 +398,35 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 }
             }
         } else {
+            // fixed burst: REPS x (N_IN inner steps, N_LF leaf steps).  INNER = 1..9 means (INNER, 1) x 1; INNER >= 100
+            // encodes REPS*100 + N_IN*10 + N_LF (e.g. 231 = two rounds of 3 inner + 1 leaf between scheduler checks).
+            constexpr int REPS = INNER >= 100 ? INNER / 100 : 1;
+            constexpr int N_IN = INNER >= 100 ? (INNER / 10) % 10 : (INNER > 0 ? INNER : 1);
+            constexpr int N_LF = INNER >= 100 ? INNER % 10 : 1;
 #pragma unroll
-            for (int k = 0; k < (INNER > 0 ? INNER : 1); k++) {
-                if (STATS) {
-                    const int n_in = __popcll(__ballot(tv.cur >= 0));
-                    if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
+            for (int r = 0; r < REPS; r++) {
+#pragma unroll
+                for (int k = 0; k < N_IN; k++) {
+                    if (STATS) {
+                        const int n_in = __popcll(__ballot(tv.cur >= 0));
+                        if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
+                    }
+                    if (tv.cur >= 0) {
+                        if (STATS) st.nodes++;
+                        ptd::inner_step<PRUNE, RES == 2, STK>(sv, ray.org, tv, stk);
+                    }
                 }
-                if (tv.cur >= 0) {
-                    if (STATS) st.nodes++;
-                    ptd::inner_step<PRUNE, RES == 2, STK>(sv, ray.org, tv, stk);
+#pragma unroll
+                for (int k = 0; k < N_LF; k++) {
+                    if (STATS) {
+                        const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != DONE));
+                        if (n_lf) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
+                    }
+                    if (tv.cur < 0 && tv.cur != DONE) {
+                        if (STATS) st.leaves++;
+                        ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
+                    }
                 }
-            }
-            if (STATS) {
-                const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != DONE));
-                if (n_lf) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
-            }
-            if (tv.cur < 0 && tv.cur != DONE) {
-                if (STATS) st.leaves++;
-                ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
             }
         }
     }

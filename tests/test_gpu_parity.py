@@ -55,7 +55,7 @@ def test_device_reproduces_golden_image(dscenes, path, trav, force_global, kerne
     assert_bit_equal(img, want, f"{name} trav={trav} global={force_global} kernel={kernel}")
 
 
-@pytest.mark.parametrize("thresh,inner,minw", [(40, -6, 6), (32, 4, 6), (40, 4, 6), (40, 3, 6)])
+@pytest.mark.parametrize("thresh,inner,minw", [(40, -6, 6), (32, 4, 6), (40, 4, 6), (40, 3, 6), (40, 162, 6)])
 def test_scheduler_variants_are_bit_identical(oracle, dscenes, thresh, inner, minw):
     """The scheduling knobs of trace_kernel_v2 change WHEN a lane runs, never what it computes."""
     hs, d = load_scene("cbox")

@@ -22,7 +22,7 @@ def variants():
     yield ("v2 auto generic", {"kernel": 2, "v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "xcd_regions": 0, "octants": 1, "specialize": 0})
     yield ("v2 auto no-oct", {"kernel": 2, "v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "xcd_regions": 0, "octants": 0, "specialize": 1})
     yield ("v2 auto 1queue", {"kernel": 2, "v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "xcd_regions": 1, "octants": 1, "specialize": 1})
-    for (t, i, w) in ((0, 0, 0), (40, -6, 6), (32, 4, 6), (40, 4, 6), (40, 3, 6)):
+    for (t, i, w) in ((0, 0, 0), (40, -6, 6), (32, 4, 6), (40, 4, 6), (40, 3, 6), (40, 162, 6)):
         yield (f"v2 T{t} I{i} W{w}", {"kernel": 2, "v2_thresh": t, "v2_inner": i, "v2_minw": w, "xcd_regions": 0, "octants": 1, "specialize": 1})
 
 
