@@ -18,7 +18,9 @@ def main(tag, scene, traversal):
     src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
-    ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    # gpurun merges new files next to those of earlier runs: only the newest file of every pass counts
+    newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
+    ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
     kern = {}
     for r in csv.DictReader(open(ks)):
@@ -26,7 +28,8 @@ def main(tag, scene, traversal):
             kern = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
     agg = collections.defaultdict(list)
     meta = {}
-    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    for pass_dir in glob.glob(os.path.join(src, "pmc_*")):
+        f = newest(os.path.join(pass_dir, "*", "*_counter_collection.csv"))
         for r in csv.DictReader(open(f)):
             if "trace_kernel" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
