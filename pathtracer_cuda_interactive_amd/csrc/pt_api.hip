@@ -313,7 +313,8 @@ LdsPlan make_plan(const pt_scene* S, int res, bool stack16) {
     uint32_t off = 0;
     if (res != 0) {
         lp.nodes_off = off;
-        off = align16(off + (uint32_t)S->dev.num_nodes * (res == 2 ? 8u : 1u) * kLdsNodeStride);
+        off = align16(off + (res == 2 ? 8u * oct_table_pitch((uint32_t)S->dev.num_nodes, kLdsNodeStride)
+                                      : (uint32_t)S->dev.num_nodes * kLdsNodeStride));
         lp.prims_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DPrim));
         lp.normals_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DNormals));
         lp.mats_off = off; off = align16(off + (uint32_t)S->dev.num_materials * sizeof(DMaterial));

@@ -132,8 +132,13 @@ template <int RES>
 __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, const LdsPlan& lp, unsigned char* smem) {
     ptd::SceneView sv;
     if (RES != 0) {
-        if (RES == 2) stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes_oct, 8u * (uint32_t)scn.num_nodes);
-        else stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
+        const uint32_t oct_pitch = oct_table_pitch((uint32_t)scn.num_nodes, kLdsNodeStride);
+        if (RES == 2) {
+            for (uint32_t o = 0; o < 8; o++)
+                stage_nodes_to_lds(smem + lp.nodes_off + o * oct_pitch, scn.nodes_oct + (size_t)o * scn.num_nodes, (uint32_t)scn.num_nodes);
+        } else {
+            stage_nodes_to_lds(smem + lp.nodes_off, scn.nodes, (uint32_t)scn.num_nodes);
+        }
         stage_to_lds(smem + lp.prims_off, scn.prims, (uint32_t)scn.num_prims * sizeof(DPrim));
         stage_to_lds(smem + lp.normals_off, scn.normals, (uint32_t)scn.num_prims * sizeof(DNormals));
         stage_to_lds(smem + lp.mats_off, scn.materials, (uint32_t)scn.num_materials * sizeof(DMaterial));
@@ -145,7 +150,7 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
         sv.materials = reinterpret_cast<const DMaterial*>(smem + lp.mats_off);
         sv.emission = reinterpret_cast<const DEmission*>(smem + lp.emis_off);
         sv.node_stride = kLdsNodeStride;
-        sv.oct_stride = RES == 2 ? (uint32_t)scn.num_nodes * kLdsNodeStride : 0u;
+        sv.oct_stride = RES == 2 ? oct_pitch : 0u;
     } else {
         sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
         sv.materials = scn.materials; sv.emission = scn.emission;

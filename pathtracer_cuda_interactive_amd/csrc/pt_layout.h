@@ -82,6 +82,17 @@ struct RenderDev {
     uint32_t chunk;                 // work items a wave reserves per atomic (64..256, multiple of 64)
 };
 
+// Bytes between the 8 ray-octant node tables in LDS.  A table of n 64-B nodes is a multiple of 64 B, so every table would
+// start at the same two bank positions; one 16-B pad makes the table pitch an odd number of 16-B units, which puts the
+// 8 tables at 8 different bank positions (lanes of a wave read nodes of different octants at once).
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline uint32_t oct_table_pitch(uint32_t num_nodes, uint32_t node_stride) {
+    const uint32_t bytes = num_nodes * node_stride;
+    return bytes + (((bytes / 16u) & 1u) ? 0u : 16u);
+}
+
 // LDS carve-up of the trace kernel (all offsets in bytes, 16-B aligned)
 struct LdsPlan {
     uint32_t nodes_off, prims_off, normals_off, mats_off, emis_off, stack_off;
