@@ -492,6 +492,13 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         rd.total_work = (uint32_t)(npix * (uint64_t)sn);
         rd.num_regions = S->opt_xcd_regions > 0 ? (int)std::min<int64_t>(S->opt_xcd_regions, 8) : 8;
         rd.rows_per_region = (rows.count + rd.num_regions - 1) / rd.num_regions;
+        rd.div_width = make_fastdiv((uint32_t)p->width);
+        rd.div_npix_full = make_fastdiv((uint32_t)rd.rows_per_region * (uint32_t)p->width);
+        {   // the band that holds the remainder rows (all bands after it are empty)
+            const int full = rows.count / rd.rows_per_region, rest = rows.count - full * rd.rows_per_region;
+            rd.short_region = rest ? full : -1;
+            rd.div_npix_last = make_fastdiv((uint32_t)std::max(rest, 1) * (uint32_t)p->width);
+        }
 
         const uint64_t blocks_needed = (rd.total_work + kBlock - 1) / kBlock;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)S->num_cus * bpc, blocks_needed));

@@ -88,9 +88,9 @@ struct PathStart {
 // main.cu:32-44 for region-local work item `item` of `region`: (sample, pixel) -> PCG stream, jitter, primary ray.
 __device__ __forceinline__ PathStart start_path(const RenderDev& rp, uint32_t region, uint32_t item) {
     const uint32_t npix_r = region_rows(rp, region) * (uint32_t)rp.width;
-    const uint32_t s_local = item / npix_r;
+    const uint32_t s_local = fastdiv(item, (int)region == rp.short_region ? rp.div_npix_last : rp.div_npix_full);   // item / npix_r
     const uint32_t pix_r = item - s_local * npix_r;
-    const uint32_t rr = pix_r / (uint32_t)rp.width;
+    const uint32_t rr = fastdiv(pix_r, rp.div_width);                                                                // pix_r / width
     const int i = (int)(pix_r - rr * (uint32_t)rp.width);
     const uint32_t local_row = region * (uint32_t)rp.rows_per_region + rr;
     const int j = rp.row_begin + (int)local_row * rp.row_step;

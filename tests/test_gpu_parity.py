@@ -265,7 +265,7 @@ def test_depth_limits(oracle, dscenes, max_depth, rr_depth):
 def test_edge_sizes(oracle, dscenes):
     hs, d = load_scene("cbox")
     ds = dscenes("cbox")
-    for w, h, spp in [(1, 1, 1), (1, 7, 2), (65, 1, 1), (3, 3, 70)]:
+    for w, h, spp in [(1, 1, 1), (1, 7, 2), (65, 1, 1), (3, 3, 70), (7, 9, 3), (641, 17, 1), (33, 8, 2), (5, 16, 1)]:
         p = hs.render_params(w, h, spp)
         assert_bit_equal(ds.render(p), oracle.render(d, p)[0], f"{w}x{h}x{spp}")
 

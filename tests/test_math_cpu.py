@@ -1,10 +1,14 @@
 """The product's arithmetic header (csrc/pt_math.h, host half of libpt_hip.so) against the oracle's
 independent restatement (oracle/pt_oracle_math.h): bit-for-bit, on the CPU.  The GPU half is checked
 by tests/test_gpu_math.py."""
+import os
+
 import numpy as np
 from conftest import assert_bit_equal
 
 from pathtracer_cuda_interactive_amd import device as dev
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_sincos_bit_exact_and_accurate(oracle):
@@ -43,3 +47,14 @@ def test_pcg_matches_oracle(oracle):
     for k in range(len(streams)):
         _, f, _ = oracle.pcg(int(streams[k]), int(seeds[k]), 2)
         assert a[k] == f[0] and b[k] == f[1]
+
+
+def test_fastdiv_matches_integer_division(tmp_path):
+    """start_path maps a work item to (sample, row, column) with multiply-shift divisions (csrc/pt_layout.h FastDiv);
+    they must agree with / for every operand below 2^30 — the launch caps work items and pixels at 2^30."""
+    import subprocess
+    exe = tmp_path / "fastdiv_check"
+    src = os.path.join(REPO, "tests", "native", "fastdiv_check.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "pathtracer_cuda_interactive_amd", "csrc"), src, "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
