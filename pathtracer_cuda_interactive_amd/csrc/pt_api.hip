@@ -41,6 +41,10 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }          // the owner makes the buffer's device current first (pt_scene_destroy)
     int ensure(size_t count) {
         if (count <= n && p) return PT_OK;
         if (p) { (void)hipFree(p); p = nullptr; n = 0; }
@@ -510,9 +514,10 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
 
         if (S->pass_events.size() <= (size_t)pass) {
             pt_scene::PassEvents fresh{};
-            HIP_TRY(hipEventCreate(&fresh.t0));
-            HIP_TRY(hipEventCreate(&fresh.t1));
-            HIP_TRY(hipEventCreate(&fresh.r1));
+            hipError_t ee = hipEventCreate(&fresh.t0);
+            if (ee == hipSuccess && (ee = hipEventCreate(&fresh.t1)) != hipSuccess) (void)hipEventDestroy(fresh.t0);
+            if (ee == hipSuccess && (ee = hipEventCreate(&fresh.r1)) != hipSuccess) { (void)hipEventDestroy(fresh.t0); (void)hipEventDestroy(fresh.t1); }
+            if (ee != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(ee));
             S->pass_events.push_back(fresh);
         }
         const pt_scene::PassEvents pe = S->pass_events[pass];
@@ -713,7 +718,6 @@ int pt_debug_math(int op, const float* x, const float* y, float* out0, float* ou
     DevBuf<float> dx, dy, d0, d1;
     int rc;
     if ((rc = dx.ensure(n)) || (rc = dy.ensure(n)) || (rc = d0.ensure(n)) || (rc = d1.ensure(n))) return rc;
-    auto cleanup = [&] { dx.release(); dy.release(); d0.release(); d1.release(); };
     hipError_t e = hipMemcpy(dx.p, x, n * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dy.p, y, n * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d1.p, 0, n * sizeof(float));
@@ -723,7 +727,6 @@ int pt_debug_math(int op, const float* x, const float* y, float* out0, float* ou
     }
     if (e == hipSuccess) e = hipMemcpy(out0, d0.p, n * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out1, d1.p, n * sizeof(float), hipMemcpyDeviceToHost);
-    cleanup();
     if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("pt_debug_math: ") + hipGetErrorString(e));
     return PT_OK;
 }
@@ -754,7 +757,6 @@ int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, flo
     DevBuf<int32_t> dp;
     int rc;
     if ((rc = dr.ensure((size_t)n * 8)) || (rc = dt.ensure((size_t)n * 3)) || (rc = dp.ensure(n))) return rc;
-    auto cleanup = [&] { dr.release(); dt.release(); dp.release(); };
     const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
     hipError_t e = hipMemcpy(dr.p, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -766,7 +768,6 @@ int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, flo
     }
     if (e == hipSuccess) e = hipMemcpy(out_tuv, dt.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_prim, dp.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
-    cleanup();
     if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("pt_debug_intersect: ") + hipGetErrorString(e));
     return PT_OK;
 }
