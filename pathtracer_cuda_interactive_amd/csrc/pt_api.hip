@@ -363,9 +363,9 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 
 // (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps, 1..9 a
 // burst of `inner` inner steps + 1 leaf step, >= 100 the encoded burst REPS*100 + N_INNER*10 + N_LEAF (pt_kernels.h).
-// Measured on MI355X (tools/gpu_tune.py, tools/gpu_ab.py, profiles/r01_tune_round*.log): LDS-resident scenes with
-// spheres are fastest with T40 / vote-6 / W6, triangle-only LDS scenes with T40 / 6 inner + 2 leaf steps / W6 (cbox 3.77 ms
-// against 3.99 with 3+1, 4.10 with 4+1, 3.92 with two rounds of 3+1; r01_tune_round21/22), scenes in global memory with
+// Measured on MI355X (tools/gpu_tune.py, tools/gpu_ab.py, profiles/r01_tune_round*.log): LDS-resident scenes are
+// fastest with T40 / 6 inner + 2 leaf steps / W6 (cbox 3.77 ms against 3.99 with 3+1, 4.10 with 4+1, 3.92 with two rounds of
+// 3+1; sphere and mixed scenes 1-6 % ahead of the vote burst they used before; r01_tune_round21/22), scenes in global memory with
 // T32 / I4 / W6 (bunny 10.7 ms; every other burst shape within 1 %).  I8 and unbounded descent are slower, T56 starves the
 // scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills)
 // is 5-8 % slower.
@@ -388,7 +388,7 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
         if (t == 0) t = res ? 40 : 32;
         const bool tri = S->tri_only && S->opt_specialize;
-        if (i == 0) i = (res && !tri) ? -6 : (res ? 162 : 4);   // vote burst only pays when leaf tests are a mix of spheres and triangles
+        if (i == 0) i = res ? 162 : 4;              // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1
         if (w == 0) w = 6;
         const int spec = !tri ? 0 : (S->diffuse_only ? 2 : 1);
         return pick_kernel_v2(res, prune, stats, spec, t, i, w);
