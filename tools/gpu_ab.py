@@ -58,7 +58,7 @@ def main():
         opts[label] = o
     scenes = sys.argv[cut + 1:]
     res = {label: [] for label, _ in libs}
-    for rnd in range(2):
+    for rnd in range(int(os.environ.get("PT_AB_ROUNDS", "2"))):
         for label, path in libs:
             env = dict(os.environ, PT_HIP_LIB=os.path.abspath(path), PT_AB_OPTIONS=opts[label])
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"] + scenes, env=env, capture_output=True, text=True, timeout=900)
