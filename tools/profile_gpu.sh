@@ -7,9 +7,12 @@ ARGS="$@"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# kernel trace: the default bench command (20 steps, 3 warm-up) so that its average agrees with bench.py's own HIP-event time;
+# counter passes: 5 steps are enough (every launch is identical)
+TRACE="python3 bench.py --no-cpu-baseline $ARGS"
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline $ARGS"
 echo "== kernel trace" | tee $OUT/log.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH >> $OUT/log.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE >> $OUT/log.txt 2>&1 || exit 1
 for PASS in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" \
