@@ -186,13 +186,14 @@ int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the sc
  *                   rounds*100 + inner*10 + leaf steps (162 = 6 inner + 2 leaf steps).  Only compiled-in variants are
  *                   accepted (PT_ERR_INVALID_ARG otherwise); every variant renders the same bits.
  *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
+ *   "top_cache"     1 (default) scenes read from global memory keep the top levels of the BVH in LDS, 0 = all from memory
  *   "xcd_regions"   0 (default) 8 row bands with XCD affinity, 1 = a single work queue
  *   "force_global"  1 = never stage the scene in LDS
  *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query)
  *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 1 GiB); larger jobs run in sample passes
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)
- * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables),
+ * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables, 3 global + top of the tree in LDS), "top_nodes",
  * "passes", "occupancy", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned". */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
 int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);

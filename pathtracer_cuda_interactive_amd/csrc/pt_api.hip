@@ -73,6 +73,12 @@ struct DeviceGuard {
 constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
 constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node table must fit in this many bytes of LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
+constexpr uint32_t kTopNodes = 512;              // scenes read from global memory: this many nodes are numbered breadth-first
+                                                 // from the root, so that [0, k) is the top of the tree for every k (LDS cache)
+#ifndef PT_TOP_LDS_KB
+#define PT_TOP_LDS_KB 31
+#endif
+constexpr uint32_t kTopLdsBudget = PT_TOP_LDS_KB * 1024;    // LDS per block that keeps 5 blocks per CU resident (160 KB / 5, minus slack)
 constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band counters, one 128-B line each
 constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
 
@@ -95,6 +101,7 @@ struct pt_scene {
     uint32_t scene_bytes = 0;
     bool tri_only = false;           // the scene holds no sphere
     bool diffuse_only = false;       // every material is DIFFUSE
+    uint32_t top_avail = 0;          // nodes [0, top_avail) are the top of the tree in breadth-first order (0 = plain pre-order)
     int bvh_depth = 0;
     // scratch
     DevBuf<float4> samples;
@@ -113,6 +120,7 @@ struct pt_scene {
     int64_t opt_stats = 0;
     int64_t opt_specialize = 1;      // compile-time specialisation on scene content (no spheres -> sphere code removed)
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
+    int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
@@ -231,6 +239,28 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             if (rn.prim == -1) todo.push_back({nd.right, it.depth + 1});
             if (ln.prim == -1) todo.push_back({nd.left, it.depth + 1});
         }
+        // Scenes too big for LDS: renumber so that the first kTopNodes ids are the top of the tree in breadth-first order
+        // (every ray starts there; the kernel keeps a prefix of them in LDS), the rest stays in pre-order.
+        if ((size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + order.size() * sizeof(DNode) > kLdsSceneLimit && order.size() > 1) {
+            // only as many as fit next to the traversal stacks (make_plan)
+            const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)(std::max(depth - 1, 1) + 1) * 64u * 4u;
+            const size_t want = std::min<size_t>(kTopNodes, kTopLdsBudget > stack_bytes ? (kTopLdsBudget - stack_bytes) / sizeof(DNode) : 0);
+            std::vector<int32_t> top;
+            std::vector<char> in_top(d->num_nodes, 0);
+            if (want) top.push_back(d->root);
+            for (size_t head = 0; head < top.size() && top.size() < want; head++) {
+                const pt_bvh_node& nd = d->nodes[top[head]];
+                for (int32_t ch : {nd.left, nd.right})
+                    if (d->nodes[ch].prim == -1 && top.size() < want) top.push_back(ch);
+            }
+            for (int32_t r : top) in_top[r] = 1;
+            std::vector<int32_t> renum(top);
+            for (int32_t r : order)
+                if (!in_top[r]) renum.push_back(r);
+            order.swap(renum);
+            for (size_t k = 0; k < order.size(); k++) inner_id[order[k]] = (int32_t)k;
+            S->top_avail = (uint32_t)top.size();
+        }
         nodes.resize(order.size());
         for (size_t k = 0; k < order.size(); k++) {
             const pt_bvh_node& nd = d->nodes[order[k]];
@@ -311,11 +341,19 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     return PT_OK;
 }
 
-// res: 0 scene in global memory, 1 scene staged in LDS, 2 staged in LDS with the 8 octant node tables
+// res: 0 scene in global memory, 1 scene staged in LDS, 2 staged in LDS with the 8 octant node tables,
+//      3 scene in global memory with the top of the tree cached in LDS
 LdsPlan make_plan(const pt_scene* S, int res, bool stack16) {
     LdsPlan lp{};
     uint32_t off = 0;
-    if (res != 0) {
+    if (res == 3) {
+        // as many top nodes as fit next to the stacks without costing a resident block
+        const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
+        const uint32_t room = kTopLdsBudget > stack_bytes ? kTopLdsBudget - stack_bytes : 0u;
+        lp.top_count = std::min<uint32_t>(S->top_avail, room / (uint32_t)sizeof(DNode));
+        lp.nodes_off = 0;
+        off = lp.top_count * (uint32_t)sizeof(DNode);
+    } else if (res != 0) {
         lp.nodes_off = off;
         off = align16(off + (res == 2 ? 8u * oct_table_pitch((uint32_t)S->dev.num_nodes, kLdsNodeStride)
                                       : (uint32_t)S->dev.num_nodes * kLdsNodeStride));
@@ -356,6 +394,7 @@ TraceFn pick_v2_r(bool prune, bool stats, int spec) {
 
 template <int THRESH, int INNER, int MINW>
 TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
+    if (res == 3) return pick_v2_r<3, THRESH, INNER, MINW>(prune, stats, spec);
     if (res == 2) return pick_v2_r<2, THRESH, INNER, MINW>(prune, stats, spec);
     if (res == 1) return pick_v2_r<1, THRESH, INNER, MINW>(prune, stats, spec);
     return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats, spec);
@@ -378,7 +417,8 @@ TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, in
 
 // Residency the next launch will use (see make_plan).
 int scene_residency(const pt_scene* S) {
-    if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit) return 0;
+    if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit)
+        return (S->top_avail > 0 && S->opt_top_cache && S->opt_kernel == 2 && !S->opt_force_global) ? 3 : 0;
     if (S->opt_kernel == 2 && S->opt_octants && S->dev.nodes_oct) return 2;
     return 1;
 }
@@ -386,14 +426,15 @@ int scene_residency(const pt_scene* S) {
 TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
     if (S->opt_kernel == 2) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
-        if (t == 0) t = res ? 40 : 32;
+        const bool lds = res == 1 || res == 2;
+        if (t == 0) t = lds ? 40 : 32;
         const bool tri = S->tri_only && S->opt_specialize;
-        if (i == 0) i = res ? 162 : 4;              // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1
+        if (i == 0) i = lds ? 162 : 4;              // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1
         if (w == 0) w = 6;
         const int spec = !tri ? 0 : (S->diffuse_only ? 2 : 1);
         return pick_kernel_v2(res, prune, stats, spec, t, i, w);
     }
-    return pick_kernel_v1(res != 0, prune, stats);
+    return pick_kernel_v1(res == 1 || res == 2, prune, stats);
 }
 
 // Sums the kCounterSlots per-workgroup counter slots of the last frame (the caller has synchronised the stream).
@@ -455,8 +496,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
     const int res = scene_residency(S);
-    const bool lds_scene = res != 0;
-    const LdsPlan lp = make_plan(S, res, res != 0 && S->opt_kernel == 2);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
+    const bool lds_scene = res == 1 || res == 2;
+    const LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel == 2);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
     TraceFn fn = pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
     if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
@@ -470,7 +511,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     const int occ = S->cfg_occ;
     // scenes read from global memory run best with at most 5 blocks per CU (more resident rays thrash L1/L2:
     // bunny 10.9 ms at 5, 11.4 ms at 7; tools/gpu_occ_test.py); LDS-resident scenes take every block they can get
-    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (res == 0 ? std::min(occ, 5) : occ);
+    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (!lds_scene ? std::min(occ, 5) : occ);
     S->info_occupancy = occ;
     S->info_lds_bytes = lp.total;
     S->info_lds_scene = lds_scene;
@@ -659,6 +700,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "stats") S->opt_stats = value;
     else if (k == "xcd_regions") S->opt_xcd_regions = value;
     else if (k == "octants") S->opt_octants = value;
+    else if (k == "top_cache") S->opt_top_cache = value;
     else if (k == "specialize") S->opt_specialize = value;
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
@@ -681,6 +723,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "bvh_depth") *value = S->bvh_depth;
     else if (k == "scene_bytes") *value = S->scene_bytes;
     else if (k == "num_inner_nodes") *value = S->dev.num_nodes;
+    else if (k == "top_nodes") *value = make_plan(S, scene_residency(S), false).top_count;
     else if (k == "device") *value = S->device;
     else if (k.rfind("diag", 0) == 0 && k.size() >= 5 && k.size() <= 7 && k.find_first_not_of("0123456789", 4) == std::string::npos &&
              std::stoi(k.substr(4)) < 8 + kNumCounters - kTimelineBase) {

@@ -127,11 +127,14 @@ __device__ __forceinline__ void stage_nodes_to_lds(void* dst, const DNode* src, 
 
 // The scene as this kernel instantiation sees it: staged into LDS by the whole workgroup (small scenes) or read in
 // place from global memory.  Must be called by every thread of the block (it contains a __syncthreads()).
-// RES = residency of the scene: 0 global memory, 1 staged in LDS, 2 staged in LDS with 8 ray-octant node tables.
+// RES = residency of the scene: 0 global memory, 1 staged in LDS, 2 staged in LDS with 8 ray-octant node tables,
+// 3 global memory with the top of the tree cached in LDS.
 template <int RES>
 __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, const LdsPlan& lp, unsigned char* smem) {
     ptd::SceneView sv;
-    if (RES != 0) {
+    sv.top_nodes = nullptr;
+    sv.top_count = 0;
+    if (RES == 1 || RES == 2) {
         const uint32_t oct_pitch = oct_table_pitch((uint32_t)scn.num_nodes, kLdsNodeStride);
         if (RES == 2) {
             for (uint32_t o = 0; o < 8; o++)
@@ -152,6 +155,12 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
         sv.node_stride = kLdsNodeStride;
         sv.oct_stride = RES == 2 ? oct_pitch : 0u;
     } else {
+        if (RES == 3) {              // top of the tree (nodes [0, top_count), breadth-first) staged next to the stacks
+            stage_to_lds(smem + lp.nodes_off, scn.nodes, lp.top_count * (uint32_t)sizeof(DNode));
+            __syncthreads();
+            sv.top_nodes = reinterpret_cast<const DNode*>(smem + lp.nodes_off);
+            sv.top_count = lp.top_count;
+        }
         sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
         sv.materials = scn.materials; sv.emission = scn.emission;
         sv.node_stride = sizeof(DNode);
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
 
     // LDS-resident scenes are small enough for 16-bit node / primitive references on the stack
     constexpr bool TRI_ONLY = SPEC >= 1, DIFFUSE_ONLY = SPEC >= 2;
-    using STK = typename std::conditional<RES != 0, int16_t, int32_t>::type;
+    using STK = typename std::conditional<RES == 1 || RES == 2, int16_t, int32_t>::type;
     constexpr int32_t DONE = ptd::done_value<STK>();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
         // the finished segments as soon as a quarter of the live lanes wait instead of waiting for the slowest traversal
         // (bunny: -1 % at 64 spp, -15 % for 2-spp frames); LDS-resident scenes gain nothing from it and keep the plain rule
         int thresh = THRESH;
-        if (RES == 0 && !work_left) thresh = min(THRESH, max(1, (__popcll(__ballot(alive)) + 3) / 4));
+        if ((RES == 0 || RES == 3) && !work_left) thresh = min(THRESH, max(1, (__popcll(__ballot(alive)) + 3) / 4));
         if (n_pend >= thresh || idle_mask == ~0ull) {
             if (n_pend == 0) break;          // every lane idle, no live path, no work left
             if (STATS) { dg_sched++; dg_sched_lanes += (unsigned)n_pend; }
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                 if (n_in >= n_lf) {
                     if (at_inner) {
                         if (STATS) st.nodes++;
-                        ptd::inner_step<PRUNE, RES == 2, STK>(sv, ray.org, tv, stk);
+                        ptd::inner_step<PRUNE, RES == 2, STK, RES == 3>(sv, ray.org, tv, stk);
                     }
                 } else if (at_leaf) {
                     if (STATS) st.leaves++;
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                     }
                     if (tv.cur >= 0) {
                         if (STATS) st.nodes++;
-                        ptd::inner_step<PRUNE, RES == 2, STK>(sv, ray.org, tv, stk);
+                        ptd::inner_step<PRUNE, RES == 2, STK, RES == 3>(sv, ray.org, tv, stk);
                     }
                 }
 #pragma unroll
@@ -489,6 +498,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     ptd::SceneView sv;
     sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
     sv.materials = scn.materials; sv.emission = scn.emission;
+    sv.top_nodes = nullptr; sv.top_count = 0;
     sv.node_stride = sizeof(DNode);
     sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
     sv.bg = ptm::mk(0, 0, 0);

@@ -43,6 +43,8 @@ struct SceneView {
     const DNode* nodes;
     uint32_t node_stride;   // bytes between consecutive nodes (64)
     uint32_t oct_stride;    // bytes between the 8 ray-octant copies of the node table; 0 = one table (see inner_step)
+    const DNode* top_nodes; // TOP kernels: LDS copy of nodes [0, top_count), the top levels of the tree in breadth-first order
+    uint32_t top_count;
     const DPrim* prims;
     const DNormals* normals;
     const DMaterial* materials;
@@ -87,13 +89,27 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
 // OCT=true: the node table exists in 8 copies, one per ray octant, in which every box is stored as (near planes,
 // far planes) for that octant — the swaps of bbox.cuh:40-55 are done once at scene-build time instead of with 12
 // selects per visit.  Same arithmetic on the same operands, so the result is bit-identical.
-template <bool PRUNE, bool OCT, class STK>
+// TOP=true (scenes read from global memory): the first sv.top_count nodes — the top levels of the tree, which every ray
+// visits — are served from an LDS copy, the rest from global memory.  Same bytes either way.
+template <bool PRUNE, bool OCT, class STK, bool TOP = false>
 __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, STK* stk) {
-    const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (OCT ? t.node_off : 0u) + (uint32_t)t.cur * sv.node_stride;
-    const float4 a = ld4(nd, 0);    // lmin.xyz lmax.x      (OCT: lnear.xyz lfar.x)
-    const float4 b = ld4(nd, 1);    // lmax.yz  rmin.xy     (OCT: lfar.yz  rnear.xy)
-    const float4 c = ld4(nd, 2);    // rmin.z   rmax.xyz    (OCT: rnear.z  rfar.xyz)
-    const float4 d = ld4(nd, 3);    // left right - -
+    float4 a, b, c, d;
+    if (TOP && (uint32_t)t.cur < sv.top_count) {
+        // explicit LDS address space: left to itself the compiler folds both branches into one flat_load on a selected
+        // pointer, which sends every node fetch — also the global ones — down the slower flat path
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const f4v lds_f4v;
+        const lds_f4v* nd = (const lds_f4v*)(reinterpret_cast<const unsigned char*>(sv.top_nodes) + (uint32_t)t.cur * (uint32_t)sizeof(DNode));
+        const f4v va = nd[0], vb = nd[1], vc = nd[2], vd = nd[3];
+        a = make_float4(va.x, va.y, va.z, va.w); b = make_float4(vb.x, vb.y, vb.z, vb.w);
+        c = make_float4(vc.x, vc.y, vc.z, vc.w); d = make_float4(vd.x, vd.y, vd.z, vd.w);
+    } else {
+        const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (OCT ? t.node_off : 0u) + (uint32_t)t.cur * sv.node_stride;
+        a = ld4(nd, 0);    // lmin.xyz lmax.x      (OCT: lnear.xyz lfar.x)
+        b = ld4(nd, 1);    // lmax.yz  rmin.xy     (OCT: lfar.yz  rnear.xy)
+        c = ld4(nd, 2);    // rmin.z   rmax.xyz    (OCT: rnear.z  rfar.xyz)
+        d = ld4(nd, 3);    // left right - -
+    }
     const V3 inv = t.inv;
     float ltn, ltf, rtn, rtf;
     if (OCT) {

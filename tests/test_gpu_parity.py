@@ -135,10 +135,37 @@ def test_octant_node_tables_do_not_change_the_image(oracle, dscenes, name):
     assert_bit_equal(without, want, name + " single table")
 
 
+@pytest.mark.parametrize("name", ["teapot", "bunny"])
+def test_top_of_tree_cache_does_not_change_the_image(oracle, dscenes, name):
+    """Scenes read from global memory keep the top levels of the BVH (breadth-first prefix of the node array) in LDS.
+    The cached copy holds the same bytes, so frames and counters must not change by a bit, with the cache or without."""
+    hs, d = load_scene(name)
+    ds = dscenes(name)
+    p = hs.render_params(64, 48, 5, seed=8)
+    want, cnt = oracle.render(d, p)
+    assert ds.info("residency") == 3 and ds.info("top_nodes") > 0
+    ds.set_option("stats", 1)
+    try:
+        cached = ds.render(p)
+        c1 = ds.counters()
+        ds.set_option("top_cache", 0)
+        assert ds.info("residency") == 0 and ds.info("top_nodes") == 0
+        plain = ds.render(p)
+        c0 = ds.counters()
+    finally:
+        ds.set_option("top_cache", 1)
+        ds.set_option("stats", 0)
+    assert_bit_equal(cached, want, name + " top of the tree in LDS")
+    assert_bit_equal(plain, want, name + " all nodes from global memory")
+    for c in (c0, c1):
+        assert (c.paths, c.segments, c.node_visits, c.leaf_tests) == (cnt.paths, cnt.segments, cnt.inner_pops, cnt.leaf_tri + cnt.leaf_sphere)
+
+
 @pytest.mark.parametrize("n_tris,n_spheres", [(30, 3), (44, 2), (46, 1), (47, 1), (60, 4), (170, 4), (186, 2), (196, 4), (400, 4)])
 def test_residency_thresholds(oracle, n_tris, n_spheres):
     """Scenes around the two size thresholds: 8 octant node tables in LDS (<= 48 inner nodes), one table in LDS
-    (<= 36 KB of scene), global memory.  Every residency must render the oracle's image."""
+    (<= 36 KB of scene), global memory with the top of the tree in LDS (3) or without (0).  Every residency must render
+    the oracle's image."""
     hs = random_scene(100 + n_tris, n_tris=n_tris, n_spheres=n_spheres)
     d = hs.finalize()
     p = hs.render_params(48, 36, 4, seed=n_tris)
@@ -147,9 +174,15 @@ def test_residency_thresholds(oracle, n_tris, n_spheres):
     try:
         res = ds.info("residency")
         inner = ds.info("num_inner_nodes")
-        expect = 2 if inner * 8 * 64 <= 24 * 1024 else (1 if ds.info("scene_bytes") <= 36 * 1024 else 0)
+        expect = 2 if inner * 8 * 64 <= 24 * 1024 else (1 if ds.info("scene_bytes") <= 36 * 1024 else 3)
         assert res == expect, (res, inner, ds.info("scene_bytes"))
         assert_bit_equal(ds.render(p), want, f"{n_tris} tris residency {res}")
+        if res == 3:
+            assert 0 < ds.info("top_nodes") <= inner
+            ds.set_option("top_cache", 0)
+            assert ds.info("residency") == 0
+            assert_bit_equal(ds.render(p), want, f"{n_tris} tris residency 0 (renumbered nodes, no cache)")
+            ds.set_option("top_cache", 1)
         if res == 2:
             ds.set_option("octants", 0)
             assert_bit_equal(ds.render(p), want, f"{n_tris} tris residency 1")
