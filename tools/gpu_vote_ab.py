@@ -1,10 +1,13 @@
+"""Vote burst against fixed bursts on LDS-resident scenes with spheres (interleaved rounds in one process).
+Usage: python tools/gpu_vote_ab.py"""
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 from pathtracer_cuda_interactive_amd import HostScene, PT_BVH_SORT_REFERENCE
 from pathtracer_cuda_interactive_amd import device as dev
 for path in ("tests/data/mixed.xml", "tests/golden/scenes/scene1_phong.pts", "tests/golden/scenes/scene1.pts"):
-    hs = HostScene.load(os.path.join("/root/repo", path))
+    hs = HostScene.load(os.path.join(REPO, path))
     ds = dev.DeviceScene(hs.finalize(PT_BVH_SORT_REFERENCE))
     p = hs.render_params(640, 480, 16)
     res = {}
