@@ -22,7 +22,11 @@
  * out for the GPU), so inputs may be freed right after it returns.
  *
  * No torch / C++ types cross this boundary.  Thread-compatible: no hidden
- * global state except the thread-local error string.
+ * global state except the thread-local error string.  A scene handle owns one
+ * set of scratch buffers, so its renders must not overlap: calls on one handle
+ * are issued from one thread at a time, and a render on another stream is
+ * enqueued only after the previous one has finished (different handles are
+ * independent).
  */
 #ifndef PT_API_H
 #define PT_API_H
