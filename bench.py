@@ -206,8 +206,11 @@ def main():
         achieved = wl["bytes_per_segment"] * seg_launch / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
+        passes = int(R.scene.info("passes"))          # frames whose per-sample scratch exceeds the budget run in sample passes
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.scene}:{args.traversal}")
+            traffic = json.load(open(tpath)).get(f"{args.scene}:{args.traversal}")   # PMC bytes per trace_kernel launch
+            if traffic is not None:
+                traffic = int(traffic * passes)         # "launch" here = one frame = `passes` trace_kernel launches
         out = {
             "metric": "Msamples/sec (rays x spp x bounces = intersect() calls per second), " + wl["label"].split(" (")[0],
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,7 +229,7 @@ def main():
                        "frame_mean": round(float(frame.mean().item()), 6)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4),
+                         "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": passes,
                          "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
                          "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
                                   "see DESIGN.md §Measurement" % R.scene.info("scene_bytes")) if R.scene.info("lds_scene") else
