@@ -192,6 +192,7 @@ int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the sc
  *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
  *   "top_cache"     1 (default) scenes read from global memory keep the top levels of the BVH in LDS, 0 = all from memory
  *   "xcd_regions"   0 (default) 8 row bands with XCD affinity, 1 = a single work queue
+ *   "item_order"    1 (default) a band is worked through row by row (all samples of a row first), 0 = sample by sample
  *   "force_global"  1 = never stage the scene in LDS
  *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query)
  *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 1 GiB); larger jobs run in sample passes

@@ -121,6 +121,7 @@ struct pt_scene {
     int64_t opt_specialize = 1;      // compile-time specialisation on scene content (no spheres -> sphere code removed)
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
+    int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
@@ -538,6 +539,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         rd.num_regions = S->opt_xcd_regions > 0 ? (int)std::min<int64_t>(S->opt_xcd_regions, 8) : 8;
         rd.rows_per_region = (rows.count + rd.num_regions - 1) / rd.num_regions;
         rd.div_width = make_fastdiv((uint32_t)p->width);
+        rd.div_spp = make_fastdiv((uint32_t)sn);
+        rd.row_major = S->opt_item_order == 1 ? 1 : 0;
         rd.div_npix_full = make_fastdiv((uint32_t)rd.rows_per_region * (uint32_t)p->width);
         {   // the band that holds the remainder rows (all bands after it are empty)
             const int full = rows.count / rd.rows_per_region, rest = rows.count - full * rd.rows_per_region;
@@ -701,6 +704,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "xcd_regions") S->opt_xcd_regions = value;
     else if (k == "octants") S->opt_octants = value;
     else if (k == "top_cache") S->opt_top_cache = value;
+    else if (k == "item_order") S->opt_item_order = value;
     else if (k == "specialize") S->opt_specialize = value;
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;

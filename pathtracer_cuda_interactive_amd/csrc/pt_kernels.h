@@ -88,10 +88,21 @@ struct PathStart {
 // main.cu:32-44 for region-local work item `item` of `region`: (sample, pixel) -> PCG stream, jitter, primary ray.
 __device__ __forceinline__ PathStart start_path(const RenderDev& rp, uint32_t region, uint32_t item) {
     const uint32_t npix_r = region_rows(rp, region) * (uint32_t)rp.width;
-    const uint32_t s_local = fastdiv(item, (int)region == rp.short_region ? rp.div_npix_last : rp.div_npix_full);   // item / npix_r
-    const uint32_t pix_r = item - s_local * npix_r;
-    const uint32_t rr = fastdiv(pix_r, rp.div_width);                                                                // pix_r / width
-    const int i = (int)(pix_r - rr * (uint32_t)rp.width);
+    uint32_t s_local, rr;
+    int i;
+    if (rp.row_major) {
+        // all samples of a row before the next row: the waves of an XCD work on a few rows of its band at a time, so the
+        // primary rays (and what they hit) of one moment come from a small part of the scene
+        const uint32_t row_s = fastdiv(item, rp.div_width);                    // item / width = row * spp + sample
+        i = (int)(item - row_s * (uint32_t)rp.width);
+        rr = fastdiv(row_s, rp.div_spp);                                       // / spp_pass
+        s_local = row_s - rr * (uint32_t)rp.spp_pass;
+    } else {
+        s_local = fastdiv(item, (int)region == rp.short_region ? rp.div_npix_last : rp.div_npix_full);   // item / npix_r
+        const uint32_t pix_r = item - s_local * npix_r;
+        rr = fastdiv(pix_r, rp.div_width);                                                                // pix_r / width
+        i = (int)(pix_r - rr * (uint32_t)rp.width);
+    }
     const uint32_t local_row = region * (uint32_t)rp.rows_per_region + rr;
     const int j = rp.row_begin + (int)local_row * rp.row_step;
     const uint64_t pixel_index = (uint64_t)j * (uint64_t)rp.width + (uint64_t)i;

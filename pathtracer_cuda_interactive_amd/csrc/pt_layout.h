@@ -103,6 +103,8 @@ struct RenderDev {
     FastDiv div_npix_full;          // / (rows_per_region * width): pixels of a full band
     FastDiv div_npix_last;          // / pixels of the last, shorter band (region `short_region`)
     int32_t short_region;           // index of the band with fewer than rows_per_region rows, or -1
+    FastDiv div_spp;                // / spp_pass
+    int32_t row_major;              // work item order inside a band: 0 = sample, row, column   1 = row, sample, column
 };
 
 // Bytes between the 8 ray-octant node tables in LDS.  A table of n 64-B nodes is a multiple of 64 B, so every table would
