@@ -26,6 +26,8 @@ for it in range(n):
     ds.set_option("xcd_regions", (it // 11) % 2)
     ds.set_option("octants", (it // 13) % 2)
     ds.set_option("specialize", (it // 17) % 2)
+    ds.set_option("top_cache", (it // 19) % 2)
+    ds.set_option("item_order", (it // 23) % 2)
     p = hs.render_params(w, h, spp)
     p.row_begin, p.row_end, p.row_stride = it % stride, h, stride
     img = ds.render(p, traversal=trav)
