@@ -435,3 +435,25 @@ def test_invalid_descriptors_and_params_return_status_codes(dscenes):
         ds.accumulate_into(p, buf.data_ptr())
     ds.set_option("scratch_bytes", 0)
     assert e.value.status == PT_ERR_UNSUPPORTED
+
+
+def test_scene_handles_release_their_device_memory():
+    """pt_scene_destroy frees everything the handle owns (scene arrays, per-sample scratch, counters, events): creating,
+    rendering and destroying many handles must not eat device memory (the reference never frees, scene.h:144-171)."""
+    import torch
+    hs, d = load_scene("teapot")
+    p = hs.render_params(96, 64, 4)
+
+    def cycle(n):
+        for _ in range(n):
+            ds = dev.DeviceScene(d)
+            ds.render(p)
+            ds.close()
+
+    cycle(3)                                        # warm-up: allocator pools, code objects
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(60)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 60 create/destroy cycles"
