@@ -288,12 +288,14 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 
 // trace_kernel_v2 — same work, different schedule: traversal is decoupled from shading.
 // Every lane runs a small state machine {traversing | waiting for the scheduler phase}.  The wave keeps
-// executing traversal steps (INNER inner-node visits + at most one leaf test per iteration) for the lanes that
-// still traverse; lanes whose traversal finished wait until at least THRESH lanes can make progress in the
+// executing traversal steps (a burst of inner-node visits and leaf tests per iteration, shaped by INNER: see the
+// burst code below) for the lanes that still traverse; lanes whose traversal finished wait until at least THRESH lanes can make progress in the
 // scheduler phase, which then (1) shades the finished segments, (2) refills dead lanes with new paths and
 // (3) starts the next traversal — so the traversal loop runs with mostly full waves instead of draining to
 // the slowest ray of every segment.  Per-lane arithmetic is untouched: results stay bit-identical.
 // SPEC = specialisation on scene content: 0 generic, 1 no spheres, 2 no spheres and only diffuse materials.
+// RES = where the scene lives (make_scene_view): 0 global memory, 1 LDS, 2 LDS with octant node tables, 3 global memory
+// with the top of the tree cached in LDS.  MINW = minimum waves per SIMD the register allocation must allow.
 template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, int SPEC>
 __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
