@@ -211,6 +211,14 @@ def main():
             traffic = json.load(open(tpath)).get(f"{args.scene}:{args.traversal}")   # PMC bytes per trace_kernel launch
             if traffic is not None:
                 traffic = int(traffic * passes)         # "launch" here = one frame = `passes` trace_kernel launches
+        # counters of the committed rocprofv3 PMC run of this config (profiles/, tools/profile_gpu.sh): static context, not re-measured here
+        pmc = None
+        ppath = os.path.join(REPO, "profiles", f"r01_{args.scene}_final_pmc.json")
+        if args.traversal == "exact" and os.path.exists(ppath):
+            dv = json.load(open(ppath)).get("derived", {})
+            pmc = {k: round(float(dv[k]), 4) for k in ("valu_issue_busy", "valu_lane_utilization", "sq_wait_any_share_of_wave_cycles",
+                                                      "lds_bank_conflict_share", "l2_hit_rate") if k in dv}
+            pmc["source"] = os.path.relpath(ppath, REPO)
         out = {
             "metric": "Msamples/sec (rays x spp x bounces = intersect() calls per second), " + wl["label"].split(" (")[0],
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +237,7 @@ def main():
                        "frame_mean": round(float(frame.mean().item()), 6)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": passes,
+                         "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": passes, "pmc": pmc,
                          "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
                          "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
                                   "see DESIGN.md §Measurement" % R.scene.info("scene_bytes")) if R.scene.info("lds_scene") else
