@@ -403,7 +403,7 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 
 // (thresh, inner, min-waves-per-SIMD) variants compiled in; inner < 0 selects the "vote" burst of -inner steps, 1..9 a
 // burst of `inner` inner steps + 1 leaf step, >= 100 the encoded burst REPS*100 + N_INNER*10 + N_LEAF (pt_kernels.h).
-// Measured on MI355X (tools/gpu_tune.py, tools/gpu_ab.py, profiles/r01_tune_round*.log): LDS-resident scenes are
+// Measured on MI355X (tests/tools/gpu_tune.py, tests/tools/gpu_ab.py, profiles/r01_tune_round*.log): LDS-resident scenes are
 // fastest with T40 / 6 inner + 2 leaf steps / W6 (cbox 3.77 ms against 3.99 with 3+1, 4.10 with 4+1, 3.92 with two rounds of
 // 3+1; sphere and mixed scenes 1-6 % ahead of the vote burst they used before; r01_tune_round21/22), scenes in global memory with
 // T32 / I4 / W6 (bunny 10.7 ms; every other burst shape within 1 %).  I8 and unbounded descent are slower, T56 starves the

@@ -1,7 +1,7 @@
 """A/B timing of differently-built libpt_hip.so files on the GPU box (build experiments that are compile-time switches).
 Each build runs in its own child process (PT_HIP_LIB selects the library), builds alternate A B A B to cancel drift,
 and every child first checks bit-exact parity against the oracle on a small frame.
-Usage: python tools/gpu_ab.py label=path/to/lib.so[:option=value,...] [label=path ...] -- scene[@spp] [scene[@spp] ...]"""
+Usage: python tests/tools/gpu_ab.py label=path/to/lib.so[:option=value,...] [label=path ...] -- scene[@spp] [scene[@spp] ...]"""
 import json
 import os
 import subprocess
@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480, 16), "teapot": (640, 480, 16),
            "buddha_standin": (1280, 960, 16), "dragon_standin": (960, 540, 16)}
 

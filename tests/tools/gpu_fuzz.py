@@ -1,9 +1,9 @@
 """Fuzz: random scenes (all materials, spheres + triangles, sizes across every residency) rendered on the GPU and with the
 oracle; frames and counters must be bit-identical in exact traversal, pruned traversal must stay within 1e-4 except for the
-rare pixels it is allowed to flip.  Usage: python tools/gpu_fuzz.py [n_scenes]"""
+rare pixels it is allowed to flip.  Usage: python tests/tools/gpu_fuzz.py [n_scenes]"""
 import os, sys, time
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import oracle_binding as ob
 from conftest import random_scene

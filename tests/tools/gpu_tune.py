@@ -1,12 +1,12 @@
 """Kernel-variant sweep on the GPU box: parity check (bit-exact vs oracle on a small frame) + interleaved
 timing rounds of the headline configs (median/min of HIP-event kernel times; §5.4 rule 24: one process).
-Usage: python tools/gpu_tune.py [scene ...]"""
+Usage: python tests/tools/gpu_tune.py [scene ...]"""
 import os
 import sys
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 import oracle_binding as ob  # noqa: E402

@@ -2,7 +2,7 @@
 In exact traversal the box tests never look at the current best hit, so a lane can put the leaves it meets into a small
 per-lane FIFO and keep visiting inner nodes; leaf steps then serve the oldest queued leaf of every lane that has one
 (the per-lane order of leaf tests — and with it the tie-breaking — is unchanged).
-Event traces come from the oracle (tools/sim_schedule.py).  Costs are wave-instruction estimates from the ISA."""
+Event traces come from the oracle (tests/tools/sim_schedule.py).  Costs are wave-instruction estimates from the ISA."""
 import sys
 
 from sim_schedule import Ray, load_paths
