@@ -195,7 +195,7 @@ int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the sc
  *   "item_order"    1 (default) a band is worked through row by row (all samples of a row first), 0 = sample by sample
  *   "force_global"  1 = never stage the scene in LDS
  *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query)
- *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 1 GiB); larger jobs run in sample passes
+ *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 8 GiB); larger jobs run in sample passes
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)
  * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables, 3 global + top of the tree in LDS), "top_nodes",
