@@ -17,8 +17,9 @@ PINS = json.load(open(os.path.join(GOLDEN, "pins.json")))
 
 @pytest.mark.parametrize("kat", PINS["pcg"], ids=lambda k: f"stream{k['stream']}")
 def test_pcg_known_answers(oracle, kat):
-    u, f, (state, inc) = oracle.pcg(kat["stream"], kat["seed"], 4)
-    assert state == kat["state"] and inc == kat["inc"]
+    u, f, (state, inc) = oracle.pcg(kat["stream"], kat["seed"], len(kat["u32"]))
+    if "state" in kat:                                  # the published pcg32-demo vector lists outputs only
+        assert state == kat["state"] and inc == kat["inc"]
     assert [int(x) for x in u] == kat["u32"]
     if "f32" in kat:
         np.testing.assert_allclose(f, np.array(kat["f32"], dtype=np.float32), rtol=0, atol=1e-9)
