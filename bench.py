@@ -5,9 +5,11 @@ path-tracing hot path on BASELINE.json's metric config — cbox 640x480 spp=64 o
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cbox|bunny|scene1] [--traversal exact|pruned]
 
 One "step" = one full frame: trace kernel(s) + ordered resolve (+ gather to rank 0 when N>1).
-N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling — the frame stays 640x480 and the
-sample count grows to 64*N, rows are interleaved over ranks (rank r: rows r, r+N, ...), so every GPU traces
-the same 19.66 M paths as the 1-GPU run; the row bands are gathered to rank 0 over RCCL inside the timed region.
+N>1 (one rank per GPU): weak scaling — the frame stays 640x480 and the sample count grows to 64*N, rows are
+interleaved over ranks (rank r: rows r, r+N, ...), so every GPU traces the same 19.66 M paths as the 1-GPU run; the
+row bands are gathered to rank 0 over RCCL inside the timed region.  `python bench.py --gpus N` starts its own N
+ranks (torch.distributed.run as a child process, before this process touches the GPU); under an external
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it runs as one of the ranks.
 
 Prints ONE JSON line (rank 0).  `value` is the whole-job rate with the scene already resident in HBM.
 """
@@ -111,6 +113,105 @@ def progressive_mode(args, hs, desc, wl):
     ds.close()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` as typed: start N ranks with torch.distributed.run as a CHILD process and relay rank 0's
+    JSON line.  Nothing in this (parent) process has imported torch.cuda or called HIP, and it never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this image
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode != 0 or line is None:
+        raise SystemExit(r.returncode or 1)
+
+
+class StubRenderer:
+    """TEST HOOK (--stub-renderer): exercises bench.py's multi-rank control flow — launcher, sharding, gather, timing
+    all-reduce, JSON — on a box without GPUs (gloo, CPU tensors).  It renders nothing: row j of the frame is filled with
+    the value j, so the assembled frame proves the de-interleave; every number in the output line is meaningless and the
+    line says `"stub": true`.  tests/test_bench_launcher.py is its only user."""
+
+    class _Scene:
+        class _C:
+            kernel_ms, resolve_ms, segments, paths = 1.0, 0.1, 0, 0
+
+        def __init__(self):
+            self.c = self._C()
+
+        def counters(self):
+            return self.c
+
+        def info(self, key):
+            return 1 if key == "passes" else 0
+
+        def close(self):
+            pass
+
+    def __init__(self, desc, hs):
+        self.scene = self._Scene()
+
+    def render(self, params, rank, world):
+        import torch
+
+        from pathtracer_cuda_interactive_amd import distributed as D
+
+        def render_rows(q):
+            rows = torch.arange(q.row_begin, q.row_end, max(q.row_stride, 1), dtype=torch.float32)
+            self.scene.c.paths = int(rows.numel()) * q.width * q.spp
+            self.scene.c.segments = 2 * self.scene.c.paths
+            return rows[:, None, None].expand(-1, q.width, 3).contiguous()
+        return D.render_sharded(render_rows, params, rank, world)
+
+    def close(self):
+        pass
+
+
+def physical_roofline(scene, traversal, lds_scene, k_ms):
+    """The bound that physically limits the trace kernel, as a fraction <= 1:
+      LDS-resident scenes  -> VALU lane throughput:  frac = (SQ_INSTS_VALU / t) / (1024 SIMDs x 2.4 GHz / 2 cycles) x lane utilisation
+      scenes in global mem -> L2-miss (fabric) bandwidth:  frac = (EA read bytes + write bytes) / t / 8 TB/s
+    Instruction and byte counts per launch come from the committed rocprofv3 PMC run of the same command
+    (profiles/rNN_<scene>_pmc.json — a launch of this config executes the same work every time); t = this run's
+    HIP-event kernel time."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{scene}_pmc.json")))
+    if traversal != "exact" or not cands:
+        return None
+    prof = json.load(open(cands[-1]))
+    c, dv = prof.get("counters_mean_per_launch", {}), prof.get("derived", {})
+    t = k_ms * 1e-3
+    src = os.path.relpath(cands[-1], REPO)
+    if lds_scene:
+        if "SQ_INSTS_VALU" not in c or "valu_lane_utilization" not in dv:
+            return None
+        peak = 1024 * 2.4e9 / 2.0                       # wave64 VALU instructions per second: 2 cycles each on a SIMD-32
+        issue = c["SQ_INSTS_VALU"] / t / peak
+        return {"bound": "valu", "frac": round(issue * dv["valu_lane_utilization"], 4),
+                "valu_issue_frac_of_peak": round(issue, 4), "lane_utilization": round(dv["valu_lane_utilization"], 4),
+                "formula": "SQ_INSTS_VALU / kernel_s / (1024 x 2.4e9 / 2) x (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))",
+                "source": src}
+    if "l2_miss_bytes_per_launch" not in dv:
+        return None
+    gbs = dv["l2_miss_bytes_per_launch"] / t / 1e9
+    return {"bound": "l2_miss_bw", "frac": round(gbs / HBM_PEAK_GBS, 4), "achieved_GBps": round(gbs, 1), "peak_GBps": HBM_PEAK_GBS,
+            "formula": "(32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B [TCC_EA0_RDREQ*] + 1024 x WRITE_SIZE) / kernel_s / 8e12; "
+                       "bytes that leave the L2 are served by the Infinity Cache or by HBM",
+            "source": src}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,10 +220,15 @@ def main():
     ap.add_argument("--scene", default="cbox", choices=sorted(WORKLOADS))
     ap.add_argument("--traversal", default="exact", choices=["exact", "pruned"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub-renderer", action="store_true",
+                    help="TEST HOOK: run the multi-rank control flow on CPU (gloo) with a renderer that renders nothing")
     ap.add_argument("--progressive", type=int, default=0, metavar="SPF",
                     help="instead of the offline frame: time render_progressive-style frames of SPF samples each "
                          "(pt_render_accumulate; the reference UI's default is 2, main.cu:131) and report frames/s")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)          # before anything in this process touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -135,15 +241,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    stub = args.stub_renderer
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
 
     if not os.path.exists(_build.HIP_LIB) or not os.path.exists(_build.HOST_LIB):
         _build.build_all()
@@ -163,7 +273,7 @@ def main():
     if args.progressive > 0:
         return progressive_mode(args, hs, desc, wl)
 
-    R = D.ShardedRenderer(desc)
+    R = StubRenderer(desc, hs) if stub else D.ShardedRenderer(desc)
     kernel_ms, resolve_ms, segs, paths = [], [], [], []
 
     def step(record):
@@ -174,10 +284,12 @@ def main():
         return frame
 
     def fence():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(False)
@@ -189,7 +301,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed, float(sum(segs)), float(sum(paths)), float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, float(sum(segs)), float(sum(paths)), float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -213,12 +325,15 @@ def main():
                 traffic = int(traffic * passes)         # "launch" here = one frame = `passes` trace_kernel launches
         # counters of the committed rocprofv3 PMC run of this config (profiles/, tools/profile_gpu.sh): static context, not re-measured here
         pmc = None
-        ppath = os.path.join(REPO, "profiles", f"r01_{args.scene}_final_pmc.json")
-        if args.traversal == "exact" and os.path.exists(ppath):
-            dv = json.load(open(ppath)).get("derived", {})
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{args.scene}_pmc.json")))
+        if args.traversal == "exact" and cands:
+            dv = json.load(open(cands[-1])).get("derived", {})
             pmc = {k: round(float(dv[k]), 4) for k in ("valu_issue_busy", "valu_lane_utilization", "sq_wait_any_share_of_wave_cycles",
                                                       "lds_bank_conflict_share", "l2_hit_rate") if k in dv}
-            pmc["source"] = os.path.relpath(ppath, REPO)
+            pmc["source"] = os.path.relpath(cands[-1], REPO)
+        lds_scene = bool(R.scene.info("lds_scene"))
+        physical = None if stub else physical_roofline(args.scene, args.traversal, lds_scene, k_ms)
         out = {
             "metric": "Msamples/sec (rays x spp x bounces = intersect() calls per second), " + wl["label"].split(" (")[0],
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,18 +347,25 @@ def main():
                        "paths_per_step": int(total_paths / args.steps), "segments_per_step": int(total_segs / args.steps),
                        "mpaths_per_s": round(total_paths / elapsed / 1e6, 2), "kernel_ms": round(k_ms, 4),
                        "resolve_ms": round(float(np.mean(resolve_ms)), 4), "lds_scene": int(R.scene.info("lds_scene")),
-                       "grid": int(R.scene.info("grid")), "blocks_per_cu": int(R.scene.info("occupancy")),
+                       "grid": int(R.scene.info("grid")), "blocks_per_cu": int(R.scene.info("blocks_per_cu")),
+                       "blocks_per_cu_occupancy_limit": int(R.scene.info("occupancy")),
                        "vgprs": int(R.scene.info("vgprs_pruned" if args.traversal == "pruned" else "vgprs")),
                        "frame_mean": round(float(frame.mean().item()), 6)},
+            # SURVEY §8d's fields, exactly as defined there: ALGORITHMIC bytes of the reference layout per second against the HBM
+            # peak (can exceed 1: those bytes are served by LDS / L1 / L2, not by HBM).  `physical` names the bound that really
+            # limits this kernel and gives a fraction <= 1 of it; `traffic` = measured L2-miss bytes per frame (PMC).
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "physical": physical,
                          "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": passes, "pmc": pmc,
                          "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
                          "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
-                                  "see DESIGN.md §Measurement" % R.scene.info("scene_bytes")) if R.scene.info("lds_scene") else
-                                 "working set (%.1f MB) is served by L2/Infinity Cache, see DESIGN.md §Measurement" % (R.scene.info("scene_bytes") / 1e6)},
+                                  "the physical bound is VALU lane throughput, see `physical` and DESIGN.md §7" % R.scene.info("scene_bytes")) if lds_scene else
+                                 "working set (%.1f MB) is served by L2/Infinity Cache: the physical bound is the L2-miss path, see `physical` and DESIGN.md §7" % (R.scene.info("scene_bytes") / 1e6)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            out["stub"] = True
+            out["config"]["frame_rows_ok"] = bool((frame[:, 0, 0] == torch.arange(wl["h"], dtype=torch.float32)).all())
+        if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(desc, hs.render_params(wl["w"], wl["h"], wl["spp"]), args.scene)
         print(json.dumps(out), flush=True)
     R.close()

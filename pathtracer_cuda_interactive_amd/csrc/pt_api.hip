@@ -128,7 +128,7 @@ struct pt_scene {
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
     // info of last launch
-    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0;
+    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
     std::vector<PassEvents> pass_events;                         // pool, reused from frame to frame
     size_t passes_timed = 0;                                     // events of the last frame: pass_events[0 .. passes_timed)
@@ -470,6 +470,14 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (!S || !p || !out_dev) return fail(PT_ERR_INVALID_ARG, "null argument");
     if (p->width <= 0 || p->height <= 0 || p->spp <= 0) return fail(PT_ERR_INVALID_ARG, "width, height and spp must be positive");
     if (p->sample_offset < 0 || p->stream_stride < 0) return fail(PT_ERR_INVALID_ARG, "negative sample_offset / stream_stride");
+    // PCG stream = pixel_index*stride + sample_offset + s: samples [sample_offset, sample_offset + spp) must stay below the
+    // stride, or pixel p's sample `stride + k` would replay pixel p+1's sample k (identical random sequences in neighbouring
+    // pixels).  With the default stride (0 -> spp) that allows sample_offset 0 only: progressive callers pass an explicit
+    // stride = any upper bound on the total sample count.
+    if ((int64_t)p->sample_offset + p->spp > (int64_t)(p->stream_stride > 0 ? p->stream_stride : p->spp))
+        return fail(PT_ERR_INVALID_ARG, p->stream_stride > 0
+                        ? "sample_offset + spp exceeds stream_stride: PCG streams of neighbouring pixels would overlap"
+                        : "sample_offset > 0 needs an explicit stream_stride >= total sample count (default stride = spp)");
     RowSel rows;
     int rc = select_rows(p, &rows);
     if (rc) return rc;
@@ -488,9 +496,23 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (npix > (1ull << 30)) return fail(PT_ERR_INVALID_ARG, "more than 2^30 pixels per call");
     // samples per pass: bounded by the scratch budget and by 2^30 work items per launch
     uint64_t scratch = S->opt_scratch_bytes > 0 ? (uint64_t)S->opt_scratch_bytes : kDefaultScratchBytes;
+    if (S->opt_scratch_bytes <= 0 && std::min<uint64_t>(scratch, npix * (uint64_t)p->spp * sizeof(float4)) > S->samples.n * sizeof(float4)) {
+        // the buffer must grow under the default budget: never to more than a quarter of what is free on the device right
+        // now, so that several handles / ranks on one GPU, or a smaller GPU, split into more passes instead of failing
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            scratch = std::min<uint64_t>(scratch, std::max<uint64_t>((uint64_t)free_b / 4, S->samples.n * sizeof(float4)));
+    }
     uint64_t spp_pass = std::max<uint64_t>(1, std::min<uint64_t>(scratch / (npix * sizeof(float4)), (1ull << 30) / npix));
     spp_pass = std::min<uint64_t>(spp_pass, (uint64_t)p->spp);
-    if ((rc = S->samples.ensure(npix * spp_pass))) return rc;
+    if (mode == 2 && spp_pass < (uint64_t)p->spp)
+        return fail(PT_ERR_UNSUPPORTED, "pt_render_accumulate: spp of one call must fit the scratch budget (single pass)");
+    // allocation failure (another handle took the memory meanwhile): halve the samples per pass and retry
+    while ((rc = S->samples.ensure(npix * spp_pass))) {
+        if (spp_pass == 1 || mode == 2) return rc;
+        (void)hipGetLastError();
+        spp_pass = (spp_pass + 1) / 2;
+    }
     const int n_pass = (int)(((uint64_t)p->spp + spp_pass - 1) / spp_pass);
     if (mode == 2 && n_pass > 1)
         return fail(PT_ERR_UNSUPPORTED, "pt_render_accumulate: spp of one call must fit the scratch budget (single pass)");
@@ -516,6 +538,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     // bunny 10.9 ms at 5, 11.4 ms at 7; tools/gpu_occ_test.py); LDS-resident scenes take every block they can get
     int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (!lds_scene ? std::min(occ, 5) : occ);
     S->info_occupancy = occ;
+    S->info_blocks_per_cu = bpc;
     S->info_lds_bytes = lp.total;
     S->info_lds_scene = lds_scene;
 
@@ -724,7 +747,8 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "lds_scene") *value = S->info_lds_scene;
     else if (k == "residency") *value = scene_residency(S);
     else if (k == "passes") *value = S->info_passes;
-    else if (k == "occupancy") *value = S->info_occupancy;
+    else if (k == "occupancy") *value = S->info_occupancy;                // what the occupancy query allows
+    else if (k == "blocks_per_cu") *value = S->info_blocks_per_cu;        // what the last launch used
     else if (k == "num_cus") *value = S->num_cus;
     else if (k == "bvh_depth") *value = S->bvh_depth;
     else if (k == "scene_bytes") *value = S->scene_bytes;

@@ -110,7 +110,7 @@ struct RenderDev {
 // Bytes between the 8 ray-octant node tables in LDS.  A table of n 64-B nodes is a multiple of 64 B, so every table would
 // start at the same two bank positions; one 16-B pad makes the table pitch an odd number of 16-B units, which puts the
 // 8 tables at 8 different bank positions (lanes of a wave read nodes of different octants at once).
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint32_t oct_table_pitch(uint32_t num_nodes, uint32_t node_stride) {

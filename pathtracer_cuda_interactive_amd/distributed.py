@@ -11,9 +11,6 @@ import torch
 import torch.distributed as dist
 
 
-_GATHER_OK = True
-
-
 def shard_params(params, rank, world):
     """pt_render_params of rank `rank`: rows rank, rank+world, ... of the full frame."""
     q = params.copy()
@@ -55,22 +52,15 @@ def render_sharded(render_rows, params, rank=None, world=None, group=None, dst=0
         pad = torch.zeros((max_rows - mine.shape[0], W, 3), dtype=mine.dtype, device=mine.device)
         mine = torch.cat([mine, pad], dim=0)
     mine = mine.contiguous()
-    global _GATHER_OK
-    if _GATHER_OK:
-        try:
-            if rank == dst:
-                parts = torch.empty((world, max_rows, W, 3), dtype=mine.dtype, device=mine.device)
-                dist.gather(mine, list(parts.unbind(0)), dst=dst, group=group)
-                return assemble(parts, H, W, world)
-            dist.gather(mine, None, dst=dst, group=group)
-            return None
-        except (RuntimeError, NotImplementedError):
-            # a backend without gather: every rank takes the same branch (the error is raised before any
-            # communication), so falling back to all_gather keeps the ranks in step
-            _GATHER_OK = False
-    parts = torch.empty((world, max_rows, W, 3), dtype=mine.dtype, device=mine.device)
-    dist.all_gather_into_tensor(parts, mine, group=group)
-    return assemble(parts, H, W, world) if rank == dst else None
+    # One collective, the same on every rank: gather to `dst`.  Both backends this runs on implement it ("nccl" = RCCL
+    # as grouped send/recv over xGMI, "gloo" for the CPU tests).  Communication errors propagate: a rank that failed must
+    # exit non-zero rather than issue a different collective from its peers.
+    if rank == dst:
+        parts = torch.empty((world, max_rows, W, 3), dtype=mine.dtype, device=mine.device)
+        dist.gather(mine, list(parts.unbind(0)), dst=dst, group=group)
+        return assemble(parts, H, W, world)
+    dist.gather(mine, None, dst=dst, group=group)
+    return None
 
 
 class ShardedRenderer:

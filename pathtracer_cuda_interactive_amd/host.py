@@ -146,6 +146,7 @@ class HostScene:
         _check(lib().pt_host_scene_finalize(self._h, int(bvh_sort_mode)))
         d = PtSceneDesc()
         _check(lib().pt_host_scene_get_desc(self._h, C.byref(d)))
+        d._owner = self          # the desc holds raw pointers into the native scene: keep it alive as long as the desc
         self._desc = d
         return d
 

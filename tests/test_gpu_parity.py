@@ -94,8 +94,12 @@ def test_device_matches_live_oracle(oracle, dscenes, name, w, h, spp):
     # work counters agree with the oracle's: same paths, same segments, same node visits / primitive tests
     assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
     assert c.node_visits == cnt.inner_pops and c.leaf_tests == cnt.leaf_tri + cnt.leaf_sphere
+    # pruned traversal is NOT guaranteed bit-exact (a triangle's t can round below its box's entry distance: DESIGN.md §6):
+    # a legitimate rounding flip may move a pixel by one path's radiance / spp, so this is a tolerance, not a bit test
     img2 = ds.render(p, traversal=PT_TRAVERSAL_PRUNED)
-    assert_bit_equal(img2, want, name + " pruned")
+    diff_px = int((np.abs(img2 - want).max(axis=2) > 0).sum())
+    assert diff_px <= 2, f"{diff_px} pixels differ between pruned and exact traversal"
+    assert abs(float(img2.mean()) - float(want.mean())) < 1e-3 * max(float(want.mean()), 1e-6)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -427,6 +431,23 @@ def test_invalid_descriptors_and_params_return_status_codes(dscenes):
     with pytest.raises(PtError) as e:
         ds.set_option("no_such_option", 1)
     assert e.value.status == PT_ERR_INVALID_ARG
+    # PCG stream = pixel*stride + sample_offset + s: samples beyond the stride would replay the next pixel's streams
+    p = hs.render_params(16, 16, 4)
+    p.sample_offset, p.stream_stride = 6, 8                       # 6 + 4 > 8
+    with pytest.raises(PtError) as e:
+        ds.render(p)
+    assert e.value.status == PT_ERR_INVALID_ARG and "stream_stride" in str(e.value)
+    import torch
+    acc = torch.zeros(16 * 16 * 3, device="cuda")
+    p = hs.render_params(16, 16, 2)                               # what pt_host_default_params produces: stride 0 -> spp
+    ds.accumulate_into(p, acc.data_ptr())                         # first frame (offset 0): fine
+    p.sample_offset = 2                                           # second frame with the default stride: streams would overlap
+    with pytest.raises(PtError) as e:
+        ds.accumulate_into(p, acc.data_ptr())
+    assert e.value.status == PT_ERR_INVALID_ARG and "explicit stream_stride" in str(e.value)
+    p.stream_stride = 1 << 16
+    ds.accumulate_into(p, acc.data_ptr())                         # explicit upper bound: accepted
+    torch.cuda.synchronize()
     import torch
     buf = torch.zeros(16 * 16 * 3, device="cuda")
     ds.set_option("scratch_bytes", 16 * 16 * 16)
