@@ -183,6 +183,20 @@ int pt_render_accumulate(pt_scene* scene, const pt_render_params* p, float* accu
 
 int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the scene's last stream */
 
+/* BVH construction on the device — an alternative producer of `pt_scene_desc.nodes` to the host's
+ * construct_bvh (bvh.cu:16-54: object-median split, O(N log^2 N), 10-57 s start-up in README.md:123,132).
+ *   PT_BVH_DEVICE_LBVH  Morton order + Karras hierarchy
+ *   PT_BVH_DEVICE_SAH   Morton order + per-node surface-area-cost cut, top-down
+ * desc->nodes / desc->root are ignored.  out_nodes receives 2*num_shapes-1 nodes in the reference's layout (HOST
+ * memory: the same array can be handed to pt_scene_create and to a CPU checker); *out_root the root's index;
+ * *out_depth (optional) the depth with leaves counting 1 (computeMaxDepth, bvh.cu:56-65); *out_build_ms (optional)
+ * the device time from primitive boxes to finished nodes (uploads and the copy back to the host excluded).
+ * Such trees visit fewer nodes per ray than the reference's; closest hits — and so images — are the same except where
+ * two primitives tie on t (the first one VISITED wins, scene.h:270).  Parity and roofline numbers use the reference tree. */
+enum { PT_BVH_DEVICE_LBVH = 0, PT_BVH_DEVICE_SAH = 1 };
+int pt_bvh_build_device(const pt_scene_desc* desc, int method, pt_bvh_node* out_nodes, int32_t* out_root,
+                        int32_t* out_depth, double* out_build_ms);
+
 /* Tuning knobs (all optional; none of them changes a bit of the rendered image):
  *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel
  *   "v2_thresh" / "v2_inner" / "v2_minw"   scheduler variant of kernel 2; 0 = automatic (by scene residency).

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/pt_api.h"
+#include "pt_internal.h"
 #include "pt_kernels.h"
 
 using namespace ptl;
@@ -28,6 +29,12 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+
+}  // namespace
+
+int pt_fail(int code, const std::string& msg) { return fail(code, msg); }
+
+namespace {
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -125,6 +132,7 @@ struct pt_scene {
     int64_t opt_specialize = 1;      // compile-time specialisation on scene content (no spheres -> sphere code removed)
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
+    int64_t opt_chunk = 0;           // work items a wave reserves per atomic (0 = automatic)
     int64_t opt_gather = 0;          // scenes in global memory: gathered node fetch through per-wave LDS tiles of 32 / 64 nodes (0 = off)
     int64_t opt_lds_budget_kb = 0;   // LDS per block for top-of-tree cache + stacks + gather tiles (0 = default of the residency)
     int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
@@ -613,10 +621,15 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         const uint64_t blocks_needed = (rd.total_work + kBlock - 1) / kBlock;
         const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)S->num_cus * bpc, blocks_needed));
         S->info_grid = grid;
-        // chunk: 256 items per reservation for full frames; smaller for small launches (interactive 1-2 spp frames) so
-        // that the items are spread over all resident waves instead of the first total/256 of them
+        // chunk: work items a wave reserves per atomic.  Big launches (a wave traces >= 2048 items): 128 — the waves of a
+        // launch run dry within two paths' time of each other instead of four (cbox -1.9 %, bunny -0.9 % against 256; 64
+        // buys nothing more and saturates the counters on cheap scenes: profiles/r02_tune_round36_*.log); mid-size
+        // launches 256; small launches (interactive 1-2 spp frames) down to 64 so that the items are spread over all
+        // resident waves instead of the first total/256 of them
         const uint64_t per_wave = rd.total_work / ((uint64_t)grid * (kBlock / 64));
-        rd.chunk = per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
+        rd.chunk = per_wave >= 2048 ? 128u
+                 : per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
+        if (S->opt_chunk > 0) rd.chunk = (uint32_t)std::min<int64_t>(kMaxChunk, std::max<int64_t>(64, (S->opt_chunk / 64) * 64));
 
         if (S->pass_events.size() <= (size_t)pass) {
             pt_scene::PassEvents fresh{};
@@ -768,6 +781,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "top_cache") S->opt_top_cache = value;
     else if (k == "gather") { if (value != 0 && value != 32 && value != 64) return fail(PT_ERR_INVALID_ARG, "gather must be 0, 32 or 64"); S->opt_gather = value; }
     else if (k == "lds_budget_kb") S->opt_lds_budget_kb = value;
+    else if (k == "chunk") S->opt_chunk = value;
     else if (k == "item_order") S->opt_item_order = value;
     else if (k == "specialize") S->opt_specialize = value;
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }

@@ -21,7 +21,7 @@ using namespace ptl;
 
 
 constexpr int kBlock = 256;          // 4 waves
-constexpr uint32_t kMaxChunk = 256;  // work items a wave reserves per atomic for big launches (RenderDev::chunk)
+constexpr uint32_t kMaxChunk = 256;  // most work items a wave reserves per atomic (RenderDev::chunk)
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -61,6 +61,8 @@ __device__ __forceinline__ void feed_init(WorkFeed& f, const RenderDev& rp) {
 }
 
 // Wave-uniform.  Makes sure a non-empty chunk is reserved unless every region is exhausted.
+// (Issuing the next reservation ahead of time, to take the atomic's round trip off the critical path, was measured and
+// rejected: the pending result costs more than it hides — cbox +5.5 %, profiles/r02_tune_round36_*.log.)
 __device__ __forceinline__ void feed_reserve(WorkFeed& f, const RenderDev& rp, uint32_t* work_counters, int lane) {
     while (f.cur >= f.end && !f.exhausted) {
         const uint32_t total = region_rows(rp, f.region) * (uint32_t)rp.width * (uint32_t)rp.spp_pass;

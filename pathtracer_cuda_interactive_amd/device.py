@@ -9,14 +9,14 @@ import os
 import numpy as np
 
 from . import _build
-from .ctypes_defs import (PT_OK, PT_TRAVERSAL_DEFAULT, PtCounters, PtError, PtRenderParams, PtSceneDesc)
+from .ctypes_defs import (PT_OK, PT_TRAVERSAL_DEFAULT, PtBvhNode, PtCounters, PtError, PtRenderParams, PtSceneDesc)
 
 _lib = None
 
 EXPORTS = [
     "pt_api_version", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_async",
     "pt_render_accumulate", "pt_get_counters", "pt_scene_set_option", "pt_scene_get_info", "pt_debug_math",
-    "pt_debug_intersect", "pt_debug_math_host",
+    "pt_debug_intersect", "pt_debug_math_host", "pt_bvh_build_device",
 ]
 
 
@@ -43,6 +43,7 @@ def lib():
         L.pt_debug_math.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
         L.pt_debug_intersect.argtypes = [vp, fp, C.c_int, C.c_int, fp, ip]
         L.pt_debug_math_host.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
+        L.pt_bvh_build_device.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(PtBvhNode), ip, ip, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -125,3 +126,24 @@ def debug_math(op, x, y=None, host=False):
     fn = lib().pt_debug_math_host if host else lib().pt_debug_math
     _check(fn(op, _fp(x), _fp(y), _fp(o0), _fp(o1), x.size))
     return o0, o1
+
+
+PT_BVH_DEVICE_LBVH, PT_BVH_DEVICE_SAH = 0, 1
+NODE_DTYPE = np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("left", "<i4"), ("right", "<i4"), ("prim", "<i4")])
+
+
+def build_bvh_device(desc, method=PT_BVH_DEVICE_SAH):
+    """Builds the BVH of `desc`'s primitives on the GPU (pt_bvh_build_device).  Returns (desc2, info): desc2 is a copy of
+    `desc` that points at the new node array (kept alive by desc2), info = {"root", "depth", "build_ms", "nodes"}."""
+    n_nodes = 2 * desc.num_shapes - 1
+    nodes = np.zeros(max(n_nodes, 1), dtype=NODE_DTYPE)
+    root, depth, ms = C.c_int32(), C.c_int32(), C.c_double()
+    _check(lib().pt_bvh_build_device(C.byref(desc), int(method), nodes.ctypes.data_as(C.POINTER(PtBvhNode)), C.byref(root),
+                                     C.byref(depth), C.byref(ms)))
+    d2 = PtSceneDesc()
+    C.memmove(C.byref(d2), C.byref(desc), C.sizeof(PtSceneDesc))
+    d2.nodes = nodes.ctypes.data_as(C.POINTER(PtBvhNode))
+    d2.num_nodes = n_nodes
+    d2.root = root.value
+    d2._keep = (nodes, desc)          # the node array, and whatever keeps the other arrays of `desc` alive
+    return d2, {"root": root.value, "depth": depth.value, "build_ms": ms.value, "nodes": nodes}

@@ -1,0 +1,135 @@
+"""BVH construction on the GPU (pt_bvh_build_device: Morton order + Karras hierarchy / per-node SAH cut).
+The tree comes back in the reference's node layout, so the ORACLE traverses the very tree the device built: a device
+image must equal the oracle's image on that tree bit for bit.  Against the reference (median-split) tree the closest
+hits are the same except where two primitives tie on t (the first one visited wins, scene.h:270)."""
+import numpy as np
+import pytest
+from conftest import SCENES, assert_bit_equal, load_scene, random_scene
+
+from pathtracer_cuda_interactive_amd import PT_BVH_SORT_REFERENCE
+from pathtracer_cuda_interactive_amd import device as dev
+
+METHODS = {"lbvh": dev.PT_BVH_DEVICE_LBVH, "sah": dev.PT_BVH_DEVICE_SAH}
+
+
+def check_tree(nodes, root, n_prims, ref_leaf_boxes):
+    """Valid cover: 2N-1 nodes, every primitive in exactly one leaf, every node reachable once from the root, every inner
+    box == the union of its children's boxes (exact: min / max do not round), leaf boxes == the host's primitive boxes."""
+    assert len(nodes) == 2 * n_prims - 1 and 0 <= root < len(nodes)
+    leaf = nodes["prim"] >= 0
+    assert int(leaf.sum()) == n_prims
+    assert np.array_equal(np.sort(nodes["prim"][leaf]), np.arange(n_prims))
+    assert (nodes["left"][leaf] == -1).all() and (nodes["right"][leaf] == -1).all()
+    inner = ~leaf
+    L, R = nodes["left"][inner], nodes["right"][inner]
+    assert (L >= 0).all() and (R >= 0).all() and (L < len(nodes)).all() and (R < len(nodes)).all()
+    refs = np.concatenate([L, R, [root]])
+    assert np.array_equal(np.sort(refs), np.arange(len(nodes)))            # every node has exactly one parent (the root: none)
+    assert np.array_equal(nodes["bmin"][inner], np.minimum(nodes["bmin"][L], nodes["bmin"][R]))
+    assert np.array_equal(nodes["bmax"][inner], np.maximum(nodes["bmax"][L], nodes["bmax"][R]))
+    order = np.argsort(nodes["prim"][leaf])
+    assert np.array_equal(nodes["bmin"][leaf][order], ref_leaf_boxes[0])
+    assert np.array_equal(nodes["bmax"][leaf][order], ref_leaf_boxes[1])
+    # depth (leaves count 1) by walking down level by level
+    depth, level = 0, np.array([root])
+    while level.size:
+        depth += 1
+        inn = level[nodes["prim"][level] < 0]
+        level = np.concatenate([nodes["left"][inn], nodes["right"][inn]])
+    return depth
+
+
+def host_leaf_boxes(hs):
+    na = hs.nodes_array()
+    lf = na[na["prim"] >= 0]
+    o = np.argsort(lf["prim"])
+    return lf["bmin"][o], lf["bmax"][o]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", sorted(METHODS))
+@pytest.mark.parametrize("name,w,h,spp", [("cbox", 96, 72, 8), ("scene1", 80, 60, 8), ("teapot", 64, 48, 3), ("bunny", 64, 48, 2),
+                                          ("tetrahedron", 33, 17, 4)])
+def test_device_built_tree_is_valid_and_renders_like_the_oracle_on_it(oracle, method, name, w, h, spp):
+    hs, d = load_scene(name)
+    d2, info = dev.build_bvh_device(d, METHODS[method])
+    depth = check_tree(info["nodes"], info["root"], d.num_shapes, host_leaf_boxes(hs))
+    assert depth == info["depth"] and depth <= 63
+    d3, info3 = dev.build_bvh_device(d, METHODS[method])                   # deterministic: same bytes again
+    assert info3["root"] == info["root"] and info3["nodes"].tobytes() == info["nodes"].tobytes()
+    p = hs.render_params(w, h, spp, seed=9)
+    want, cnt = oracle.render(d2, p)                                       # the oracle on the DEVICE-built tree
+    ds = dev.DeviceScene(d2)
+    try:
+        ds.set_option("stats", 1)
+        img = ds.render(p)
+        c = ds.counters()
+        assert ds.info("bvh_depth") == depth
+    finally:
+        ds.close()
+    assert_bit_equal(img, want, f"{name} {method}")
+    assert (c.paths, c.segments, c.node_visits) == (cnt.paths, cnt.segments, cnt.inner_pops)
+    # same closest hits as on the reference tree, except for ties on t: at most a handful of pixels may differ
+    ref_img, ref_cnt = oracle.render(d, p)
+    diff_px = int((np.abs(ref_img - want).max(axis=2) > 0).sum())
+    assert diff_px <= max(2, w * h // 500), f"{diff_px} pixels differ from the reference tree's image"
+    if name in ("teapot", "bunny"):       # the point of a better tree: fewer boxes touched per ray (exact traversal never prunes)
+        assert cnt.inner_pops < 0.7 * ref_cnt.inner_pops, (cnt.inner_pops / cnt.segments, ref_cnt.inner_pops / ref_cnt.segments)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", sorted(METHODS))
+def test_device_bvh_on_random_scenes_with_spheres_and_duplicates(oracle, method):
+    """Spheres + triangles, and a mesh instanced twice at the same place (equal centroids -> equal Morton codes)."""
+    hs = random_scene(5, n_tris=60, n_spheres=5)
+    rng = np.random.default_rng(1)
+    P = rng.random((9, 3)).astype(np.float32)
+    I = np.arange(9, dtype=np.int32).reshape(3, 3)
+    for _ in range(3):                                                     # three coincident copies
+        hs.add_mesh(P, I, 0)
+    d = hs.finalize()
+    d2, info = dev.build_bvh_device(d, METHODS[method])
+    check_tree(info["nodes"], info["root"], d.num_shapes, host_leaf_boxes(hs))
+    p = hs.render_params(48, 36, 4, seed=3)
+    want, _ = oracle.render(d2, p)
+    ds = dev.DeviceScene(d2)
+    try:
+        assert_bit_equal(ds.render(p), want, "random scene " + method)
+    finally:
+        ds.close()
+
+
+@pytest.mark.gpu
+def test_single_primitive_and_bad_arguments():
+    from pathtracer_cuda_interactive_amd import PT_ERR_BAD_SCENE, PT_ERR_INVALID_ARG, HostScene, PtError
+    hs = HostScene()
+    hs.set_camera((0, 0, 3), (0, 0, 0), (0, 1, 0), 40.0, 16, 16, 1)
+    m = hs.add_material(0, (0.5, 0.5, 0.5))
+    hs.add_sphere((0, 0, 0), 1.0, m)
+    d = hs.finalize()
+    d2, info = dev.build_bvh_device(d, dev.PT_BVH_DEVICE_LBVH)
+    assert info["root"] == 0 and info["depth"] == 1 and info["nodes"]["prim"][0] == 0
+    assert np.array_equal(info["nodes"]["bmin"][0], np.float32([-1, -1, -1]))
+    with pytest.raises(PtError) as e:
+        dev.build_bvh_device(d, 7)
+    assert e.value.status == PT_ERR_INVALID_ARG
+    _, dc = load_scene("cbox")
+    import ctypes as C
+    from pathtracer_cuda_interactive_amd.ctypes_defs import PtSceneDesc
+    bad = PtSceneDesc()
+    C.memmove(C.byref(bad), C.byref(dc), C.sizeof(PtSceneDesc))
+    bad.num_shapes = 0
+    with pytest.raises(PtError) as e:
+        dev.build_bvh_device(bad, dev.PT_BVH_DEVICE_SAH)
+    assert e.value.status == PT_ERR_BAD_SCENE
+
+
+def test_without_a_gpu_the_device_builder_refuses():
+    from conftest import _gpu_available
+    from pathtracer_cuda_interactive_amd import PT_ERR_NO_DEVICE, PtError
+    if _gpu_available():
+        pytest.skip("a GPU is present")
+    _, d = load_scene("cbox")
+    with pytest.raises(PtError) as e:
+        dev.build_bvh_device(d, dev.PT_BVH_DEVICE_LBVH)
+    assert e.value.status == PT_ERR_NO_DEVICE
