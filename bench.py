@@ -347,6 +347,7 @@ def main():
                        "paths_per_step": int(total_paths / args.steps), "segments_per_step": int(total_segs / args.steps),
                        "mpaths_per_s": round(total_paths / elapsed / 1e6, 2), "kernel_ms": round(k_ms, 4),
                        "resolve_ms": round(float(np.mean(resolve_ms)), 4), "lds_scene": int(R.scene.info("lds_scene")),
+                       "lds_bytes": int(R.scene.info("lds_bytes")),
                        "grid": int(R.scene.info("grid")), "blocks_per_cu": int(R.scene.info("blocks_per_cu")),
                        "blocks_per_cu_occupancy_limit": int(R.scene.info("occupancy")),
                        "vgprs": int(R.scene.info("vgprs_pruned" if args.traversal == "pruned" else "vgprs")),

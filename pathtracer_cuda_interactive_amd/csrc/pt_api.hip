@@ -89,7 +89,6 @@ constexpr uint32_t kTopNodes = 512;              // scenes read from global memo
 #endif
 constexpr uint32_t kTopLdsBudget = PT_TOP_LDS_KB * 1024;    // LDS per block that keeps 5 blocks per CU resident (160 KB / 5, minus slack)
 constexpr uint32_t kMaxLdsBudget = 64 * 1024;               // the breadth-first numbered prefix is sized for the largest budget an option may ask for
-constexpr uint32_t kGatherLdsBudget = 39 * 1024;            // gathered node fetch: 4 blocks per CU (160 KB / 4, minus slack)
 constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band counters, one 128-B line each
 constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
 
@@ -133,8 +132,7 @@ struct pt_scene {
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
     int64_t opt_chunk = 0;           // work items a wave reserves per atomic (0 = automatic)
-    int64_t opt_gather = 0;          // scenes in global memory: gathered node fetch through per-wave LDS tiles of 32 / 64 nodes (0 = off)
-    int64_t opt_lds_budget_kb = 0;   // LDS per block for top-of-tree cache + stacks + gather tiles (0 = default of the residency)
+    int64_t opt_lds_budget_kb = 0;   // scenes in global memory: LDS per block for traversal stacks + top-of-tree cache (0 = 31 KB: 5 blocks per CU)
     int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
@@ -361,19 +359,14 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
 LdsPlan make_plan(const pt_scene* S, int res, bool stack16) {
     LdsPlan lp{};
     uint32_t off = 0;
-    if (res >= 3) {
-        // as many top nodes as fit next to the stacks (and the gather tiles) within the block's LDS budget
+    if (res == 3) {
+        // as many top nodes as fit next to the stacks within the block's LDS budget (default: without costing a resident block)
         const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
-        const uint32_t cap = res == 5 ? 64u : 32u;
-        lp.gather_stride = res >= 4 ? cap * (uint32_t)sizeof(DNode) + 64u * 4u : 0u;
-        const uint32_t fixed = stack_bytes + (uint32_t)(kBlock / 64) * lp.gather_stride;
-        const uint32_t budget = S->opt_lds_budget_kb > 0 ? (uint32_t)S->opt_lds_budget_kb * 1024u : (res >= 4 ? kGatherLdsBudget : kTopLdsBudget);
-        const uint32_t room = budget > fixed ? budget - fixed : 0u;
+        const uint32_t budget = S->opt_lds_budget_kb > 0 ? (uint32_t)S->opt_lds_budget_kb * 1024u : kTopLdsBudget;
+        const uint32_t room = budget > stack_bytes ? budget - stack_bytes : 0u;
         lp.top_count = std::min<uint32_t>(S->top_avail, room / (uint32_t)sizeof(DNode));
         lp.nodes_off = 0;
         off = lp.top_count * (uint32_t)sizeof(DNode);
-        lp.gather_off = off;
-        off += (uint32_t)(kBlock / 64) * lp.gather_stride;
     } else if (res != 0) {
         lp.nodes_off = off;
         off = align16(off + (res == 2 ? 8u * oct_table_pitch((uint32_t)S->dev.num_nodes, kLdsNodeStride)
@@ -413,22 +406,6 @@ TraceFn pick_v2_r(bool prune, bool stats, int spec) {
     return pick_v2_rt<RES, THRESH, INNER, MINW, 0>(prune, stats);
 }
 
-// variants that exist only for scenes read from global memory (INNER <= -100: memory-pipeline-aware schedule)
-template <int THRESH, int INNER, int MINW>
-TraceFn pick_v2_global(int res, bool prune, bool stats, int spec) {
-    if (res == 3) return pick_v2_r<3, THRESH, INNER, MINW>(prune, stats, spec);
-    if (res == 0) return pick_v2_r<0, THRESH, INNER, MINW>(prune, stats, spec);
-    return nullptr;
-}
-
-// gathered node fetch (residency 4 / 5): fixed bursts only
-template <int THRESH, int INNER, int MINW>
-TraceFn pick_v2_gather(int res, bool prune, bool stats, int spec) {
-    if (res == 4) return pick_v2_r<4, THRESH, INNER, MINW>(prune, stats, spec);
-    if (res == 5) return pick_v2_r<5, THRESH, INNER, MINW>(prune, stats, spec);
-    return nullptr;
-}
-
 template <int THRESH, int INNER, int MINW>
 TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
     if (res == 3) return pick_v2_r<3, THRESH, INNER, MINW>(prune, stats, spec);
@@ -446,27 +423,16 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 // scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills)
 // is 5-8 % slower.
 TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
-    if (res >= 4) {
-#define PT_V2GA(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_gather<T, I, W>(res, prune, stats, spec);
-        PT_V2GA(32, 4, 6) PT_V2GA(32, 2, 6) PT_V2GA(32, 3, 6) PT_V2GA(24, 4, 6) PT_V2GA(40, 4, 6)
-#undef PT_V2GA
-        return nullptr;
-    }
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
 #undef PT_V2
-#define PT_V2G(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_global<T, I, W>(res, prune, stats, spec);
-    PT_V2G(32, -108, 6)
-#undef PT_V2G
     return nullptr;
 }
 
 // Residency the next launch will use (see make_plan).
 int scene_residency(const pt_scene* S) {
-    if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit) {
-        if (!(S->top_avail > 0 && S->opt_top_cache && S->opt_kernel == 2 && !S->opt_force_global)) return 0;
-        return S->opt_gather == 64 ? 5 : S->opt_gather == 32 ? 4 : 3;
-    }
+    if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit)
+        return (S->top_avail > 0 && S->opt_top_cache && S->opt_kernel == 2 && !S->opt_force_global) ? 3 : 0;
     if (S->opt_kernel == 2 && S->opt_octants && S->dev.nodes_oct) return 2;
     return 1;
 }
@@ -779,7 +745,6 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "xcd_regions") S->opt_xcd_regions = value;
     else if (k == "octants") S->opt_octants = value;
     else if (k == "top_cache") S->opt_top_cache = value;
-    else if (k == "gather") { if (value != 0 && value != 32 && value != 64) return fail(PT_ERR_INVALID_ARG, "gather must be 0, 32 or 64"); S->opt_gather = value; }
     else if (k == "lds_budget_kb") S->opt_lds_budget_kb = value;
     else if (k == "chunk") S->opt_chunk = value;
     else if (k == "item_order") S->opt_item_order = value;

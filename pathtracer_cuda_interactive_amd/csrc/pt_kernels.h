@@ -141,8 +141,7 @@ __device__ __forceinline__ void stage_nodes_to_lds(void* dst, const DNode* src, 
 // The scene as this kernel instantiation sees it: staged into LDS by the whole workgroup (small scenes) or read in
 // place from global memory.  Must be called by every thread of the block (it contains a __syncthreads()).
 // RES = residency of the scene: 0 global memory, 1 staged in LDS, 2 staged in LDS with 8 ray-octant node tables,
-// 3 global memory with the top of the tree cached in LDS, 4 / 5 like 3 with the gathered node fetch through per-wave
-// LDS tiles of 32 / 64 nodes (pt_trace.h: inner_step_gather).
+// 3 global memory with the top of the tree cached in LDS.
 template <int RES>
 __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, const LdsPlan& lp, unsigned char* smem) {
     ptd::SceneView sv;
@@ -169,7 +168,7 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
         sv.node_stride = kLdsNodeStride;
         sv.oct_stride = RES == 2 ? oct_pitch : 0u;
     } else {
-        if (RES >= 3) {              // top of the tree (nodes [0, top_count), breadth-first) staged next to the stacks
+        if (RES == 3) {              // top of the tree (nodes [0, top_count), breadth-first) staged next to the stacks
             stage_to_lds(smem + lp.nodes_off, scn.nodes, lp.top_count * (uint32_t)sizeof(DNode));
             __syncthreads();
             sv.top_nodes = reinterpret_cast<const DNode*>(smem + lp.nodes_off);
@@ -330,13 +329,6 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
     tv.cur = DONE; tv.sp = 1; tv.node_off = 0;
     ptd::stack_init(stk);
-    constexpr bool GATHER = RES == 4 || RES == 5;
-    constexpr int GATHER_CAP = RES == 5 ? 64 : 32;
-    static_assert(!GATHER || INNER > 0, "the gathered node fetch is built for the fixed burst only");
-    ptd::GatherLds gl;
-    gl.tile = (ptd::lds_u8_t*)(smem + lp.gather_off + (uint32_t)wave * lp.gather_stride);
-    gl.list = (ptd::lds_vu32_t*)(smem + lp.gather_off + (uint32_t)wave * lp.gather_stride + GATHER_CAP * (uint32_t)sizeof(DNode));
-    gl.top = (ptd::lds_u8_t*)(smem + lp.nodes_off);
     ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
     ptm::Pcg rng;
     rng.state = 0; rng.inc = 1;
@@ -363,7 +355,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
         // the finished segments as soon as a quarter of the live lanes wait instead of waiting for the slowest traversal
         // (bunny: -1 % at 64 spp, -15 % for 2-spp frames); LDS-resident scenes gain nothing from it and keep the plain rule
         int thresh = THRESH;
-        if ((RES == 0 || RES >= 3) && !work_left) thresh = min(THRESH, max(1, (__popcll(__ballot(alive)) + 3) / 4));
+        if ((RES == 0 || RES == 3) && !work_left) thresh = min(THRESH, max(1, (__popcll(__ballot(alive)) + 3) / 4));
         if (n_pend >= thresh || idle_mask == ~0ull) {
             if (n_pend == 0) break;          // every lane idle, no live path, no work left
             if (STATS) { dg_sched++; dg_sched_lanes += (unsigned)n_pend; }
@@ -412,45 +404,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             }
         }
         // ---- traversal burst
-        if ((RES == 3 || RES == 0) && INNER <= -100) {
-            // Scenes read from global memory, "memory-pipeline-aware" schedule.  What binds this kernel is not latency but
-            // the CU's texture addresser: a dwordx4 wave-instruction occupies it for 16 cycles however few lanes are
-            // active (PMC on bunny: TA busy 89 %, ~20 active lanes per vector-memory instruction).  So the three step
-            // kinds are separated and the two that load from global memory run only with as many lanes as can be had:
-            //   A  inner visit served from the LDS copy of the top of the tree: no vector memory — run while any lane is there
-            //   B  inner visit of a node in global memory (4 loads)      } one of the two per round: the kind more lanes wait
-            //   C  leaf test (3 loads)                                   } for (a lane never waits for more than one round)
-            // -INNER - 100 = A steps per round at most.  Per-lane order of visits is untouched: bit-identical results.
-            constexpr int MAX_A = -INNER - 100;
-            const uint32_t top_count = sv.top_count;
-            for (int k = 0; k < MAX_A; k++) {
-                const bool at_top = (uint32_t)tv.cur < top_count;
-                const unsigned long long m_top = __ballot(at_top);
-                if (m_top == 0) break;
-                if (STATS) { dg_in++; dg_in_lanes += (unsigned)__popcll(m_top); dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
-                if (at_top) {
-                    if (STATS) st.nodes++;
-                    ptd::inner_step<PRUNE, false, STK, (RES == 3 ? 2 : 0)>(sv, ray.org, tv, stk);
-                }
-            }
-            const bool at_glob = tv.cur >= (int32_t)top_count;
-            const bool at_leaf = tv.cur < 0 && tv.cur != DONE;
-            const int n_gl = __popcll(__ballot(at_glob));
-            const int n_lf = __popcll(__ballot(at_leaf));
-            if (n_gl >= n_lf) {
-                if (STATS && n_gl) { dg_in++; dg_in_lanes += (unsigned)n_gl; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
-                if (at_glob) {
-                    if (STATS) st.nodes++;
-                    ptd::inner_step<PRUNE, false, STK, 0>(sv, ray.org, tv, stk);
-                }
-            } else {
-                if (STATS) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
-                if (at_leaf) {
-                    if (STATS) st.leaves++;
-                    ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
-                }
-            }
-        } else if (INNER < 0) {
+        if (INNER < 0) {
             // "vote" schedule: each step runs the step kind (inner-node visit or leaf test) that more lanes wait for
 #pragma unroll
             for (int k = 0; k < -INNER; k++) {
@@ -486,13 +440,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                         const int n_in = __popcll(__ballot(tv.cur >= 0));
                         if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE)); }
                     }
-                    if (GATHER) {
-                        const bool at_inner = tv.cur >= 0;
-                        if (__any(at_inner)) {
-                            const bool did = ptd::inner_step_gather<PRUNE, STK, GATHER_CAP>(sv, ray.org, tv, stk, gl, lane, at_inner);
-                            if (STATS && did) st.nodes++;
-                        }
-                    } else if (tv.cur >= 0) {
+                    if (tv.cur >= 0) {
                         if (STATS) st.nodes++;
                         ptd::inner_step<PRUNE, RES == 2, STK, (RES == 3 ? 1 : 0)>(sv, ray.org, tv, stk);
                     }

@@ -122,8 +122,7 @@ inline uint32_t oct_table_pitch(uint32_t num_nodes, uint32_t node_stride) {
 struct LdsPlan {
     uint32_t nodes_off, prims_off, normals_off, mats_off, emis_off, stack_off;
     uint32_t total;
-    uint32_t top_count;             // residency 3+: nodes [0, top_count) — the top of the tree — are also kept in LDS at nodes_off
-    uint32_t gather_off, gather_stride;   // residency 4/5: per-wave node tile + id list of the gathered fetch (pt_trace.h)
+    uint32_t top_count;             // residency 3: nodes [0, top_count) — the top of the tree — are also kept in LDS at nodes_off
 };
 
 }  // namespace ptl

@@ -93,8 +93,9 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
 // visits — are served from an LDS copy, the rest from global memory.  Same bytes either way.
 //   TOP = 0  one table (global memory, or LDS for staged scenes)
 //   TOP = 1  per lane: LDS copy when cur < top_count, else global memory (both sides may execute in one step)
-//   TOP = 2  LDS copy only — the caller guarantees cur < top_count for every active lane (top-of-tree step)
-// A step that holds only global-memory lanes is TOP = 0 (the caller guarantees cur >= top_count).
+// (Measured and rejected in round 2, all bit-exact: separate step kinds for LDS-served / global-memory / leaf visits,
+// +39..+111 % time; a gathered fetch — node ids compacted through LDS, quad-coalesced LDS-DMA into per-wave tiles —
+// +30..+50 %; child references loaded as a dwordx2, +1.5..+4 %: profiles/r02_tune_round34..37_*.log)
 // Everything of an inner visit after the node has been fetched (a, b, c, d = the node's four 16-B pieces).
 template <bool PRUNE, bool OCT, class STK>
 __device__ __forceinline__ void visit_node(const float4 a, const float4 b, const float4 c, const float4 d, const V3& o, Trav& t, STK* stk) {
@@ -166,7 +167,7 @@ __device__ __forceinline__ void ld_node_lds(const P* p, float4& a, float4& b, fl
 template <bool PRUNE, bool OCT, class STK, int TOP = 0>
 __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Trav& t, STK* stk) {
     float4 a, b, c, d;
-    if (TOP == 2 || (TOP == 1 && (uint32_t)t.cur < sv.top_count)) {
+    if (TOP == 1 && (uint32_t)t.cur < sv.top_count) {
         ld_node_lds(reinterpret_cast<const unsigned char*>(sv.top_nodes) + (uint32_t)t.cur * (uint32_t)sizeof(DNode), a, b, c, d);
     } else {
         const void* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (OCT ? t.node_off : 0u) + (uint32_t)t.cur * sv.node_stride;
@@ -176,63 +177,6 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
         d = ld4(nd, 3);    // left right - -
     }
     visit_node<PRUNE, OCT, STK>(a, b, c, d, o, t, stk);
-}
-
-// ---- gathered node fetch (scenes read from global memory) -------------------------------------------------------
-// What binds the plain per-lane fetch is the CU's vector-memory front end, not latency: a dwordx4 wave-instruction
-// occupies the texture addresser for 16 cycles however few of its lanes are active, and every active lane is a tag
-// lookup of its own (rocprofv3 on bunny: TA busy 89 % of the kernel, ~23 global-memory lanes per node fetch of
-// 4 instructions).  Here the wave first COMPACTS the nodes it needs: the lanes that stand at a node in global memory
-// rank themselves (ballot + mbcnt) and write their node ids to a list in LDS; then each LDS-DMA wave-instruction
-// (global_load_lds_dwordx4: lane l's 16 B land at tile + 16*l) fetches 16 nodes — the four lanes of a quad read the
-// four 16-B pieces of ONE node, a coalesced 64-B read and one tag lookup — so n nodes take ceil(n/16) instructions
-// instead of 4, and the node with rank r lands in tile slot r, from where its lane reads it back like a node of the
-// top-of-tree cache.  "LDS-staged node tiles for coalesced reads": same bytes, same arithmetic, bit-identical.
-typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
-typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
-
-struct GatherLds {
-    lds_u8_t* tile;          // CAP slots of 64 B, this wave's
-    lds_vu32_t* list;        // CAP node ids, this wave's
-    lds_u8_t* top;           // the workgroup's copy of the top of the tree
-};
-
-template <bool PRUNE, class STK, int CAP>
-__device__ __forceinline__ bool inner_step_gather(const SceneView& sv, const V3& o, Trav& t, STK* stk, const GatherLds& g,
-                                                  const int lane, const bool at_inner) {
-    const bool glob = at_inner && t.cur >= (int32_t)sv.top_count;
-    const unsigned long long m = __ballot(glob);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    const bool sel = glob && rank < (uint32_t)CAP;
-    if (m != 0) {                                                     // wave-uniform
-        const uint32_t n = min((uint32_t)__popcll(m), (uint32_t)CAP);
-        lds_vu32_t* list = g.list;
-        if (sel) list[rank] = (uint32_t)t.cur;
-        __builtin_amdgcn_wave_barrier();                              // LDS executes a wave's accesses in order
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(sv.nodes) + (uint32_t)(lane & 3) * 16u;
-#pragma unroll
-        for (int k = 0; k < CAP / 16; k++) {
-            if ((uint32_t)k * 16u < n) {                              // wave-uniform
-                const uint32_t slot = (uint32_t)k * 16u + ((uint32_t)lane >> 2);
-                if (slot < n) {
-                    const uint32_t id = list[slot];
-                    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (size_t)id * sizeof(DNode)),
-                                                     (lds_void_t*)(g.tile + k * 1024), 16, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const bool go = at_inner && (!glob || sel);       // lanes beyond the tile's capacity wait for the next step
-    if (go) {
-        const lds_u8_t* src = glob ? g.tile + rank * (uint32_t)sizeof(DNode) : g.top + (uint32_t)t.cur * (uint32_t)sizeof(DNode);
-        float4 a, b, c, d;
-        ld_node_lds(src, a, b, c, d);
-        visit_node<PRUNE, false, STK>(a, b, c, d, o, t, stk);
-    }
-    return go;
 }
 
 // One leaf visit (requires t.cur < 0 && t.cur != done_value<STK>()): primitive test, keep the hit if strictly closer, pop.
