@@ -138,8 +138,19 @@ typedef struct pt_render_params {
     int32_t  sample_offset;          /* first absolute sample index of this call (progressive) */
     int32_t  stream_stride;          /* PCG stream = pixel_index*stream_stride + sample_offset + s; 0 -> spp */
     int32_t  traversal;              /* PT_TRAVERSAL_* */
-    int32_t  reserved;
+    int32_t  flags;                  /* PT_RENDER_* bits; 0 = the reference's estimator */
 } pt_render_params;
+
+/* pt_render_params.flags */
+enum {
+    /* Next-event estimation — an EXTENSION, the reference samples no light (its point lights are parsed,
+     * light.h:5-8, and never used; its occlusion query is dead code, scene.h:306-330).  Every non-specular hit samples one
+     * entry of scene.lights[] uniformly (area lights: a uniform point on the emitting primitive; point lights) and
+     * connects to it with a shadow ray; emission found by BSDF sampling then counts only on camera rays and after
+     * specular bounces.  Same expectation as the reference's estimator when all light comes from area lights, less
+     * noise; point lights start to light the scene.  Off by default; every parity and roofline number is taken without it. */
+    PT_RENDER_NEE = 1
+};
 
 enum {
     PT_TRAVERSAL_DEFAULT = 0,        /* library picks (currently EXACT) */

@@ -65,6 +65,7 @@ static void counters_add(o_counters* a, const o_counters* b) {
     a->term_maxdepth += b->term_maxdepth;
     if (b->max_stack > a->max_stack) a->max_stack = b->max_stack;
     a->stack_overflow += b->stack_overflow;
+    a->shadow_rays += b->shadow_rays; a->nee_hits += b->nee_hits;
 }
 
 static int validate(const pt_scene_desc* sc, const pt_render_params* p) {

@@ -48,6 +48,7 @@ typedef struct pt_oracle_counters {
     uint64_t rng_draws, emit;
     uint64_t term_miss, term_rr, term_absorb, term_maxdepth;
     uint64_t max_stack, stack_overflow;
+    uint64_t shadow_rays, nee_hits;     /* PT_RENDER_NEE: occlusion queries traced / light samples that arrived */
     double   seconds;       /* wall time of the pixel loop only */
     int32_t  threads_used;
     int32_t  pad;

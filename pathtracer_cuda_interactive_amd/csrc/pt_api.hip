@@ -107,6 +107,7 @@ struct pt_scene {
     DevBuf<DNormals> normals;
     DevBuf<DMaterial> materials;
     DevBuf<DEmission> emission;
+    DevBuf<DLight> lights;
     SceneDev dev{};
     uint32_t scene_bytes = 0;
     bool tri_only = false;           // the scene holds no sphere
@@ -308,6 +309,15 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         const pt_light& src = d->lights[l];
         emis[l] = DEmission{src.radiance[0], src.radiance[1], src.radiance[2], src.type == PT_LIGHT_DIFFUSE_AREA ? 1 : 0};
     }
+    std::vector<DLight> dlights(std::max(d->num_lights, 1));
+    std::memset(dlights.data(), 0, sizeof(DLight) * dlights.size());
+    for (int l = 0; l < d->num_lights; l++) {
+        const pt_light& src = d->lights[l];
+        dlights[l] = DLight{src.radiance[0], src.radiance[1], src.radiance[2], src.type == PT_LIGHT_DIFFUSE_AREA ? 1 : 0,
+                            src.position[0], src.position[1], src.position[2], src.shape_id};
+        if (src.type == PT_LIGHT_DIFFUSE_AREA && (src.shape_id < 0 || src.shape_id >= N))
+            return fail(PT_ERR_BAD_SCENE, "area light refers to a shape that does not exist");
+    }
     if (nodes.empty()) nodes.resize(1);   // single-primitive scene: no inner nodes; keep a dummy so pointers are valid
 
     int rc;
@@ -331,6 +341,8 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     if ((rc = S->normals.ensure(normals.size()))) return rc;
     if ((rc = S->materials.ensure(mats.size()))) return rc;
     if ((rc = S->emission.ensure(emis.size()))) return rc;
+    if ((rc = S->lights.ensure(dlights.size()))) return rc;
+    HIP_TRY(hipMemcpy(S->lights.p, dlights.data(), dlights.size() * sizeof(DLight), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->nodes.p, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->prims.p, prims.data(), prims.size() * sizeof(DPrim), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->normals.p, normals.data(), normals.size() * sizeof(DNormals), hipMemcpyHostToDevice));
@@ -339,7 +351,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
 
     SceneDev& dv = S->dev;
     dv.nodes = S->nodes.p; dv.nodes_oct = nodes_oct.empty() ? nullptr : S->nodes_oct.p; dv.prims = S->prims.p; dv.normals = S->normals.p;
-    dv.materials = S->materials.p; dv.emission = S->emission.p;
+    dv.materials = S->materials.p; dv.emission = S->emission.p; dv.lights = S->lights.p;
     dv.num_nodes = (int32_t)nodes.size();
     dv.num_prims = N;
     dv.num_materials = d->num_materials;
@@ -427,6 +439,20 @@ TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, in
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
 #undef PT_V2
     return nullptr;
+}
+
+// Kernels with next-event estimation (PT_RENDER_NEE): exact traversal, the default schedule of the residency, generic
+// scene content or triangles-with-diffuse-materials only.
+template <int RES, int THRESH, int INNER>
+TraceFn pick_nee_r(bool stats, int spec) {
+    if (spec == 2) return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, 6, 2, true> : trace_kernel_v2<RES, false, false, THRESH, INNER, 6, 2, true>;
+    return stats ? trace_kernel_v2<RES, false, true, THRESH, INNER, 6, 0, true> : trace_kernel_v2<RES, false, false, THRESH, INNER, 6, 0, true>;
+}
+TraceFn pick_kernel_nee(int res, bool stats, int spec) {
+    if (res == 3) return pick_nee_r<3, 32, 4>(stats, spec);
+    if (res == 2) return pick_nee_r<2, 40, 162>(stats, spec);
+    if (res == 1) return pick_nee_r<1, 40, 162>(stats, spec);
+    return pick_nee_r<0, 32, 4>(stats, spec);
 }
 
 // Residency the next launch will use (see make_plan).
@@ -535,7 +561,12 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     const bool lds_scene = res == 1 || res == 2;
     const LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel == 2);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
-    TraceFn fn = pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
+    if (p->flags & ~PT_RENDER_NEE) return fail(PT_ERR_INVALID_ARG, "unknown bits in pt_render_params.flags");
+    const bool nee = (p->flags & PT_RENDER_NEE) != 0;
+    if (nee && (S->opt_kernel != 2 || traversal != PT_TRAVERSAL_EXACT))
+        return fail(PT_ERR_UNSUPPORTED, "PT_RENDER_NEE runs on the default kernel with exact traversal only");
+    TraceFn fn = nee ? pick_kernel_nee(res, S->opt_stats != 0, (S->tri_only && S->diffuse_only && S->opt_specialize) ? 2 : 0)
+                     : pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
     if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
     if (S->cfg_fn != reinterpret_cast<const void*>(fn) || S->cfg_lds != lp.total) {
         if (lp.total > 64 * 1024)
@@ -672,7 +703,7 @@ int pt_scene_destroy(pt_scene* S) {
     (void)guard.enter(S->device);
     if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
     S->nodes.release(); S->nodes_oct.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
-    S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->ctl.release();
+    S->lights.release(); S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->ctl.release();
     S->drop_events();
     delete S;
     return PT_OK;

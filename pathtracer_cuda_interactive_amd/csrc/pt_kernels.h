@@ -179,6 +179,7 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
         sv.node_stride = sizeof(DNode);
         sv.oct_stride = 0;
     }
+    sv.lights = scn.lights;
     sv.num_emission = scn.num_emission;
     sv.root_ref = scn.root_ref;
     sv.bg = ptm::mk(scn.bg[0], scn.bg[1], scn.bg[2]);
@@ -298,7 +299,9 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 // SPEC = specialisation on scene content: 0 generic, 1 no spheres, 2 no spheres and only diffuse materials.
 // RES = where the scene lives (make_scene_view): 0 global memory, 1 LDS, 2 LDS with octant node tables, 3 global memory
 // with the top of the tree cached in LDS.  MINW = minimum waves per SIMD the register allocation must allow.
-template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, int SPEC>
+// NEE = built with next-event estimation (PT_RENDER_NEE): a lane alternates between closest-hit traversals and the
+// any-hit traversal of its light sample's shadow ray; the same step functions serve both.
+template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, int SPEC, bool NEE = false>
 __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
                                                           uint32_t* __restrict__ work_counter,
@@ -337,6 +340,12 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
     uint32_t n_paths = 0, n_segs = 0;
     ptd::TravStats st;
     st.nodes = 0; st.leaves = 0;
+    // next-event estimation: the lane is tracing the shadow ray of its light sample; what it resumes with afterwards
+    ptd::NeeState nee;
+    nee.count_emission = true; nee.want_shadow = false;
+    nee.ls.wl = ptm::mk(0, 0, 1); nee.ls.tfar = 0; nee.ls.contrib = ptm::mk(0, 0, 0);
+    bool in_shadow = false, cont_after = false;
+    ptm::V3 next_dir = ptm::mk(0, 0, 1);
 
     // schedule diagnostics (STATS builds only; wave-uniform, kept in scalar registers):
     // [4] loop iterations  [5] scheduler phases  [6] lanes served by scheduler phases
@@ -362,13 +371,27 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             // (1) finish the segments whose traversal completed (radiance.cuh:26-75)
             if (idle && alive) {
                 bool cont = false;
-                if (tv.best.prim < 0) {
+                if (NEE && in_shadow) {
+                    // the shadow ray of the last bounce's light sample has been traced: add it if it arrived, then go on
+                    // with the bounce that was prepared at the same time (or end the path there)
+                    if (tv.best.prim < 0) L = L + nee.ls.contrib;
+                    in_shadow = false;
+                    cont = cont_after;
+                    if (cont) { ray.dir = next_dir; ray.tnear = 1e-4f; ray.tfar = FLT_MAX; }
+                } else if (tv.best.prim < 0) {
                     L = L + T * sv.bg;
                 } else {
                     const ptd::Surface sf = ptd::make_surface<TRI_ONLY>(sv, ray, tv.best);
-                    cont = ptd::shade_and_bounce<DIFFUSE_ONLY>(sv, sf, ray, rng, L, T, depth, rp.rr_depth);
+                    cont = ptd::shade_and_bounce<DIFFUSE_ONLY, NEE>(sv, sf, ray, rng, L, T, depth, rp.rr_depth, NEE ? &nee : nullptr);
                     depth++;
                     if (depth >= rp.max_depth) cont = false;
+                    if (NEE && nee.want_shadow) {
+                        in_shadow = true;
+                        cont_after = cont;
+                        next_dir = ray.dir;
+                        ray.dir = nee.ls.wl; ray.tnear = 1e-4f; ray.tfar = nee.ls.tfar;     // ray.org = the hit point already
+                        cont = true;
+                    }
                 }
                 if (!cont) {
                     samples[my_w] = make_float4(L.x, L.y, L.z, 0.0f);
@@ -393,6 +416,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                         depth = 0;
                         alive = true;
                         n_paths++;
+                        if (NEE) { nee.count_emission = true; in_shadow = false; }
                     }
                     feed.cur += min(n, avail);
                 }
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
             // (3) start the next traversal (scene.h:247-256)
             if (idle && alive) {
                 ptd::trav_begin(sv, ray, tv);
-                n_segs++;
+                if (!(NEE && in_shadow)) n_segs++;          // "segments" = intersect() calls; shadow rays are not counted
             }
         }
         // ---- traversal burst
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                     }
                 } else if (at_leaf) {
                     if (STATS) st.leaves++;
-                    ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
+                    ptd::leaf_step<STK, TRI_ONLY, NEE>(sv, ray, tv, stk, NEE && in_shadow);
                 }
             }
         } else {
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, Re
                     }
                     if (tv.cur < 0 && tv.cur != DONE) {
                         if (STATS) st.leaves++;
-                        ptd::leaf_step<STK, TRI_ONLY>(sv, ray, tv, stk);
+                        ptd::leaf_step<STK, TRI_ONLY, NEE>(sv, ray, tv, stk, NEE && in_shadow);
                     }
                 }
             }
@@ -512,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ptd::SceneView sv;
     sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
-    sv.materials = scn.materials; sv.emission = scn.emission;
+    sv.materials = scn.materials; sv.emission = scn.emission; sv.lights = scn.lights;
     sv.top_nodes = nullptr; sv.top_count = 0;
     sv.node_stride = sizeof(DNode);
     sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;

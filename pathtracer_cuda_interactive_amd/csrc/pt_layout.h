@@ -53,6 +53,14 @@ struct alignas(16) DEmission {      // 16 B: scene.lights[id] as radiance.cuh:36
     int32_t is_area;                // light.type == DIFFUSEAREALIGHT
 };
 
+struct alignas(16) DLight {         // 32 B: scene.lights[k] as next-event estimation samples it (PT_RENDER_NEE)
+    float r, g, b;                  // area: unused (the emitting primitive's own light entry decides); point: intensity
+    int32_t type;                   // PT_LIGHT_POINT / PT_LIGHT_DIFFUSE_AREA
+    float px, py, pz;               // point light position
+    int32_t shape_id;               // area light: emitting primitive
+};
+static_assert(sizeof(DLight) == 32, "DLight must be 32 bytes");
+
 struct SceneDev {
     const DNode* nodes;
     const DNode* nodes_oct;         // 8 octant-specialised copies [8][num_nodes] (small scenes only), else nullptr
@@ -60,6 +68,7 @@ struct SceneDev {
     const DNormals* normals;
     const DMaterial* materials;
     const DEmission* emission;
+    const DLight* lights;           // [num_emission] entries of scene.lights[] in order (next-event estimation only)
     int32_t num_nodes, num_prims, num_materials, num_emission;
     int32_t root_ref;
     int32_t stack_cap;              // entries per lane needed (= BVH depth)

@@ -49,6 +49,7 @@ struct SceneView {
     const DNormals* normals;
     const DMaterial* materials;
     const DEmission* emission;
+    const DLight* lights;   // global memory (next-event estimation)
     int32_t num_emission;
     int32_t root_ref;
     V3 bg;
@@ -181,8 +182,9 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
 
 // One leaf visit (requires t.cur < 0 && t.cur != done_value<STK>()): primitive test, keep the hit if strictly closer, pop.
 // TRI_ONLY: the scene holds no sphere, the sphere branch is compiled out.
-template <class STK, bool TRI_ONLY>
-__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk) {
+// ANYHIT (kernels built with next-event estimation): a lane tracing a shadow ray (`shadow`) stops at the first hit.
+template <class STK, bool TRI_ONLY, bool ANYHIT = false>
+__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk, const bool shadow = false) {
     const int32_t prim = ~t.cur;
     const DPrim* pr = sv.prims + prim;
     const float4 a = ld4(pr, 0);
@@ -239,6 +241,7 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             }
         }
     }
+    if (ANYHIT && shadow && t.best.prim >= 0) t.sp = 1;      // occluded: drop the rest of the stack, the pop below ends the traversal
     t.sp--;                       // sentinel at the stack bottom: popping an empty stack yields kDone
     t.cur = stk[t.sp * 64];
 }
@@ -339,20 +342,153 @@ __device__ __forceinline__ V3 sample_cos_n_hemisphere(float ux, float uy, float 
     return mk(cs * sin_theta, sn * sin_theta, cos_theta);
 }
 
+// ---- next-event estimation (an extension, see include/pt_api.h PT_RENDER_NEE) --------------------------
+// Mirrors oracle/pt_oracle_core.inc nee_sample / nee_brdf expression for expression (bit parity).
+struct LightSample {
+    V3 wl;             // unit direction to the light
+    float tfar;        // shadow ray extent
+    V3 contrib;        // radiance to add if the shadow ray arrives
+};
+
+// eval_brdf (scene.h:364-412) for direction wl, divided by the probability of the lobe the estimator is in
+__device__ __forceinline__ V3 nee_brdf(int32_t mtype, V3 refl, float eta, float exponent, V3 n, V3 wi, V3 wl) {
+    if (mtype == 0) {
+        const float c = fmax2(dot(wl, n), 0.0f) / kPi;
+        return refl * c;
+    }
+    if (mtype == 2) {
+        const float q = (eta - 1.0f) / (eta + 1.0f);
+        const float F0s = q * q;
+        const float p5 = pow5(1.0f - dot(n, wi));
+        const V3 F0 = mk(F0s, F0s, F0s);
+        const V3 F = F0 + (mk(1.0f, 1.0f, 1.0f) - F0) * p5;
+        const float c = fmax2(dot(wl, n), 0.0f) / kPi;
+        const V3 value = ((mk(1.0f, 1.0f, 1.0f) - F) * refl) * c;
+        return value * (1.0f / (1.0f - F.x));
+    }
+    if (mtype == 3) {
+        const V3 r = (-wi) + n * (2.0f * dot(wi, n));
+        const float r_dot = dot(r, wl), n_dot = dot(n, wl);
+        if (r_dot > 0.0f && n_dot > 0.0f) {
+            const float resp = ((exponent + 1.0f) / (2.0f * kPi)) * pow_det(r_dot, exponent);
+            return refl * resp;
+        }
+    }
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+// One light sample at p (normal n faces wi).  Draws: 1 (which light) + 2 (where on an area light).
+__device__ __forceinline__ bool nee_sample(const SceneView& sv, int32_t mtype, V3 refl, float eta, float exponent,
+                                           V3 p, V3 n, V3 wi, V3 T, Pcg& rng, LightSample& out) {
+    const int nl = sv.num_emission;
+    if (nl <= 0) return false;
+    const float xi = pcg_float(rng);
+    int k = (int)(xi * (float)nl);
+    if (k > nl - 1) k = nl - 1;
+    const float4 l0 = ld4(sv.lights + k, 0);
+    const float4 l1 = ld4(sv.lights + k, 1);
+    V3 x, le;
+    float geom;
+    if (__builtin_bit_cast(int32_t, l0.w) == 0) {                  // PT_LIGHT_POINT
+        x = mk(l1.x, l1.y, l1.z);
+        le = mk(l0.x, l0.y, l0.z);
+        geom = 1.0f;
+        const V3 dv = x - p;
+        const float d2 = dot(dv, dv);
+        if (!(d2 > 0.0f)) return false;
+        const float d = __builtin_sqrtf(d2);
+        const float invd = 1.0f / d;
+        const V3 wl = dv * invd;
+        const V3 f = nee_brdf(mtype, refl, eta, exponent, n, wi, wl);
+        if (!(max_elem(f) > 0.0f)) return false;
+        const float w = ((float)nl * geom) / d2;
+        out.contrib = T * ((f * le) * w);
+        out.wl = wl;
+        out.tfar = d;
+        return true;
+    }
+    const float u1 = pcg_float(rng);
+    const float u2 = pcg_float(rng);
+    const int32_t prim = __builtin_bit_cast(int32_t, l1.w);
+    const DPrim* pr = sv.prims + prim;
+    const float4 a = ld4(pr, 0);
+    const float4 b = ld4(pr, 1);
+    const float4 c = ld4(pr, 2);
+    // radiance a BSDF-sampled ray would pick up on this primitive (radiance.cuh:35-43 incl. the parsed-light-id quirk)
+    const int32_t lid = __builtin_bit_cast(int32_t, c.z);
+    if (!(lid >= 0 && lid < sv.num_emission)) return false;
+    const float4 e = ld4(sv.emission + lid, 0);
+    if (__builtin_bit_cast(int32_t, e.w) == 0) return false;
+    le = mk(e.x, e.y, e.z);
+    V3 nx, ng;
+    float area;
+    if (__builtin_bit_cast(int32_t, c.y) < 0) {                    // sphere
+        const float z = 1.0f - 2.0f * u1;
+        const float r = __builtin_sqrtf(clamp01(1.0f - z * z));
+        const float phi = kTwoPi * u2;
+        float sn, cs;
+        sincos_det(phi, sn, cs);
+        nx = mk(r * cs, r * sn, z);
+        ng = nx;
+        x = mk(a.x, a.y, a.z) + nx * a.w;
+        area = (4.0f * kPi) * (a.w * a.w);
+    } else {
+        const V3 p0 = mk(a.x, a.y, a.z), p1 = mk(a.w, b.x, b.y), p2 = mk(b.z, b.w, c.x);
+        const float su = __builtin_sqrtf(u1);
+        const float bu = su * (1.0f - u2), bv = su * u2, bw = 1.0f - su;
+        x = (p0 * bw + p1 * bu) + p2 * bv;
+        const V3 cr = cross(p1 - p0, p2 - p0);
+        const float len = __builtin_sqrtf(dot(cr, cr));
+        if (!(len > 0.0f)) return false;
+        const float invl = 1.0f / len;
+        ng = cr * invl;
+        area = 0.5f * len;
+        const DNormals* nr = sv.normals + prim;
+        const float4 na = ld4(nr, 0);
+        const float4 nb = ld4(nr, 1);
+        const float4 nc = ld4(nr, 2);
+        const V3 n0 = mk(na.x, na.y, na.z), n1 = mk(na.w, nb.x, nb.y), n2 = mk(nb.z, nb.w, nc.x);
+        nx = normalize((n0 * bw + n1 * bu) + n2 * bv);
+    }
+    const V3 dv = x - p;
+    const float d2 = dot(dv, dv);
+    if (!(d2 > 0.0f)) return false;
+    const float d = __builtin_sqrtf(d2);
+    const float invd = 1.0f / d;
+    const V3 wl = dv * invd;
+    if (!(dot(-wl, nx) > 0.0f)) return false;                      // radiance.cuh:38: emits towards dot(-ray.dir, n) > 0 only
+    const float cosg = __builtin_fabsf(dot(wl, ng));
+    geom = cosg * area;
+    const V3 f = nee_brdf(mtype, refl, eta, exponent, n, wi, wl);
+    if (!(max_elem(f) > 0.0f)) return false;
+    const float w = ((float)nl * geom) / d2;
+    out.contrib = T * ((f * le) * w);
+    out.wl = wl;
+    out.tfar = d * (1.0f - 1e-4f);
+    return true;
+}
+
 // One bounce of radiance() after a hit (radiance.cuh:32-74): emission, BSDF sampling,
 // throughput update, next ray, Russian roulette.  Returns false when the path ends.
 // DIFFUSE_ONLY: every material of the scene is DIFFUSE; the mirror / plastic / Phong code (and the registers its fp64
 // pow needs) is compiled out.
-template <bool DIFFUSE_ONLY>
+// Per-path state of next-event estimation that lives across scheduler phases (kernels built with NEE only).
+struct NeeState {
+    bool count_emission;   // emission found by BSDF sampling counts on camera rays and after specular bounces only
+    bool want_shadow;      // out: the light sample of this bounce needs its shadow ray traced
+    LightSample ls;        // out: that ray and the radiance it carries
+};
+
+template <bool DIFFUSE_ONLY, bool NEE = false>
 __device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surface& sf, Ray& ray, Pcg& rng,
-                                                 V3& L, V3& T, int depth, int rr_depth) {
+                                                 V3& L, V3& T, int depth, int rr_depth, NeeState* nee = nullptr) {
     V3 n = sf.n;
     const V3 wi = -ray.dir;
     const float wi_n = dot(wi, n);
     // radiance.cuh:35-43 — lights[] indexed by the parsed light id
     if (sf.light >= 0 && sf.light < sv.num_emission) {
         const float4 e = ld4(sv.emission + sf.light, 0);
-        if (__builtin_bit_cast(int32_t, e.w) != 0 && wi_n > 0.0f) L = L + T * mk(e.x, e.y, e.z);
+        if (__builtin_bit_cast(int32_t, e.w) != 0 && wi_n > 0.0f && (!NEE || nee->count_emission)) L = L + T * mk(e.x, e.y, e.z);
     }
     if (wi_n < 0.0f) n = -n;
 
@@ -361,26 +497,37 @@ __device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surf
     const float4 m1 = ld4(mp, 1);
     const int32_t mtype = __builtin_bit_cast(int32_t, m0.x);
     const V3 refl = mk(m0.y, m0.z, m0.w);
-    V3 wo;
+    bool have_light = false, specular = false;
+    if (NEE) {
+        // the light sample is drawn first (draw order: light, BSDF, roulette) and used only if the bounce turns out
+        // non-specular (PLASTIC decides below); MIRROR has no non-specular lobe
+        nee->want_shadow = false;
+        if ((DIFFUSE_ONLY || mtype != 1))
+            have_light = nee_sample(sv, DIFFUSE_ONLY ? 0 : mtype, refl, m1.x, m1.y, sf.p, n, wi, T, rng, nee->ls);
+    }
+    V3 wo = mk(0.0f, 0.0f, 0.0f);
+    bool ok = true;                                      // false: the BSDF sample carries nothing, the path ends (radiance.cuh:49-63)
     if (DIFFUSE_ONLY || mtype == 0) {                   // DIFFUSE: scene.h:429-433 + 370-375
         const float ux = pcg_float(rng);
         const float uy = pcg_float(rng);
         wo = to_world_about(n, sample_cos_hemisphere(ux, uy));
         const float c = fmax2(dot(wo, n), 0.0f) / kPi;
         const V3 value = refl * c;
-        if (!(max_elem(value) > 0.0f && c > 0.0f)) return false;
-        T = T * (value * (1.0f / c));
+        if (!(max_elem(value) > 0.0f && c > 0.0f)) ok = false;
+        else T = T * (value * (1.0f / c));
     } else if (mtype == 1) {                            // MIRROR: scene.h:434-438
+        specular = true;
         wo = reflect_about(wi, n);
         const V3 F = schlick(refl, dot(n, wo));
-        if (!(max_elem(F) > 0.0f)) return false;
-        T = T * F;
+        if (!(max_elem(F) > 0.0f)) ok = false;
+        else T = T * F;
     } else if (mtype == 2) {                            // PLASTIC: scene.h:439-454 + 379-389
         const float q = (m1.x - 1.0f) / (m1.x + 1.0f);
         const float F0s = q * q;
         const V3 F = schlick(mk(F0s, F0s, F0s), dot(n, wi));
         const float xi = pcg_float(rng);
         if (xi <= F.x) {
+            specular = true;
             wo = reflect_about(wi, n);
             // weight (1,1,1): throughput *= 1
             T = T * mk(1.0f, 1.0f, 1.0f);
@@ -391,8 +538,8 @@ __device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surf
             const float c = fmax2(dot(wo, n), 0.0f) / kPi;
             const V3 value = ((mk(1.0f, 1.0f, 1.0f) - F) * refl) * c;
             const float pdf = (1.0f - F.x) * c;
-            if (!(max_elem(value) > 0.0f && pdf > 0.0f)) return false;
-            T = T * (value * (1.0f / pdf));
+            if (!(max_elem(value) > 0.0f && pdf > 0.0f)) ok = false;
+            else T = T * (value * (1.0f / pdf));
         }
     } else {                                            // PHONG: scene.h:455-460 + 390-408
         const float ux = pcg_float(rng);
@@ -401,13 +548,22 @@ __device__ __forceinline__ bool shade_and_bounce(const SceneView& sv, const Surf
         wo = to_world_about(r, sample_cos_n_hemisphere(ux, uy, m1.y));
         const float r_dot_wo = dot(r, wo);
         const float n_dot_wo = dot(n, wo);
-        if (!(r_dot_wo > 0.0f && n_dot_wo > 0.0f)) return false;
-        const float resp = ((m1.y + 1.0f) / (2.0f * kPi)) * pow_det(r_dot_wo, m1.y);
-        const V3 value = refl * resp;
-        if (!(max_elem(value) > 0.0f && resp > 0.0f)) return false;
-        T = T * (value * (1.0f / resp));
+        if (!(r_dot_wo > 0.0f && n_dot_wo > 0.0f)) {
+            ok = false;
+        } else {
+            const float resp = ((m1.y + 1.0f) / (2.0f * kPi)) * pow_det(r_dot_wo, m1.y);
+            const V3 value = refl * resp;
+            if (!(max_elem(value) > 0.0f && resp > 0.0f)) ok = false;
+            else T = T * (value * (1.0f / resp));
+        }
+    }
+    if (NEE) {
+        // the light sample stands whether or not the BSDF sample carries on (the oracle adds it before the absorb test)
+        nee->want_shadow = have_light && !specular;
+        nee->count_emission = specular;
     }
     ray.org = sf.p;
+    if (!ok) return false;
     ray.dir = wo;
     ray.tnear = 1e-4f;
     ray.tfar = FLT_MAX;

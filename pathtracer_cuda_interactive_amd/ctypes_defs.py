@@ -15,6 +15,7 @@ PT_MAT_DIFFUSE, PT_MAT_MIRROR, PT_MAT_PLASTIC, PT_MAT_PHONG = 0, 1, 2, 3
 PT_LIGHT_POINT, PT_LIGHT_DIFFUSE_AREA = 0, 1
 PT_TRAVERSAL_DEFAULT, PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED = 0, 1, 2
 PT_BVH_SORT_TOTAL, PT_BVH_SORT_REFERENCE = 0, 1
+PT_RENDER_NEE = 1
 
 STATUS_NAMES = {
     0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_BAD_SCENE", 3: "PT_ERR_DEVICE", 4: "PT_ERR_NO_DEVICE",
@@ -60,7 +61,7 @@ class PtRenderParams(C.Structure):
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("row_stride", C.c_int32),
                 ("seed", C.c_uint64), ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
                 ("sample_offset", C.c_int32), ("stream_stride", C.c_int32), ("traversal", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
     def copy(self):
         out = PtRenderParams()

@@ -24,7 +24,7 @@ class OracleCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("paths", "segments", "inner_pops", "leaf_tri", "leaf_sphere", "valid_hits", "closer_hits", "closer_tri",
                  "rng_draws", "emit", "term_miss", "term_rr", "term_absorb", "term_maxdepth", "max_stack",
-                 "stack_overflow")] + [("seconds", C.c_double), ("threads_used", C.c_int32), ("pad", C.c_int32),
+                 "stack_overflow", "shadow_rays", "nee_hits")] + [("seconds", C.c_double), ("threads_used", C.c_int32), ("pad", C.c_int32),
                                        ("trace", C.c_void_p), ("trace_len", C.c_uint64), ("trace_cap", C.c_uint64)]
 
     def as_dict(self):
