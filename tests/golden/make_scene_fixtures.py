@@ -12,6 +12,7 @@ REF = "/root/reference/scenes"
 SCENES = {
     "scene1": "spheres/scene1.xml",
     "scene1_phong": "spheres/scene1_spherical_light_phong.xml",
+    "scene4": "spheres/scene4.xml",
     "cbox": "cbox/cbox.xml",
     "bunny": "bunny/bunny.xml",
     "teapot": "teapot/teapot_constant.xml",
