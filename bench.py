@@ -50,7 +50,7 @@ def cpu_baseline(desc, params, name):
     ob.build()
     t0 = time.perf_counter()
     total_paths = params.width * params.height * params.spp
-    budget = 20e6 if name != "cbox" and name != "scene1" else total_paths     # ~0.3-0.6 Mpaths/s/core on mesh scenes
+    budget = 60e6 if name != "cbox" and name != "scene1" else total_paths     # ~0.15-0.4 Mpaths/s/core on mesh scenes: 10-30 s on 16 cores
     if total_paths > budget:       # bound the sample: every k-th row of the frame at full spp
         k = int(np.ceil(total_paths / budget))
         q = params.copy()
@@ -179,13 +179,13 @@ class StubRenderer:
         pass
 
 
-def physical_roofline(scene, traversal, lds_scene, k_ms):
+def physical_roofline(scene, traversal, lds_scene, k_ms, launches):
     """The bound that physically limits the trace kernel, as a fraction <= 1:
       LDS-resident scenes  -> VALU lane throughput:  frac = (SQ_INSTS_VALU / t) / (1024 SIMDs x 2.4 GHz / 2 cycles) x lane utilisation
       scenes in global mem -> L2-miss (fabric) bandwidth:  frac = (EA read bytes + write bytes) / t / 8 TB/s
     Instruction and byte counts per launch come from the committed rocprofv3 PMC run of the same command
     (profiles/rNN_<scene>_pmc.json — a launch of this config executes the same work every time); t = this run's
-    HIP-event kernel time."""
+    HIP-event kernel time of one frame, which is `launches` trace_kernel launches when the frame runs in sample passes."""
     import glob
     cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{scene}_pmc.json")))
     if traversal != "exact" or not cands:
@@ -198,14 +198,14 @@ def physical_roofline(scene, traversal, lds_scene, k_ms):
         if "SQ_INSTS_VALU" not in c or "valu_lane_utilization" not in dv:
             return None
         peak = 1024 * 2.4e9 / 2.0                       # wave64 VALU instructions per second: 2 cycles each on a SIMD-32
-        issue = c["SQ_INSTS_VALU"] / t / peak
+        issue = c["SQ_INSTS_VALU"] * launches / t / peak
         return {"bound": "valu", "frac": round(issue * dv["valu_lane_utilization"], 4),
                 "valu_issue_frac_of_peak": round(issue, 4), "lane_utilization": round(dv["valu_lane_utilization"], 4),
                 "formula": "SQ_INSTS_VALU / kernel_s / (1024 x 2.4e9 / 2) x (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))",
                 "source": src}
     if "l2_miss_bytes_per_launch" not in dv:
         return None
-    gbs = dv["l2_miss_bytes_per_launch"] / t / 1e9
+    gbs = dv["l2_miss_bytes_per_launch"] * launches / t / 1e9
     return {"bound": "l2_miss_bw", "frac": round(gbs / HBM_PEAK_GBS, 4), "achieved_GBps": round(gbs, 1), "peak_GBps": HBM_PEAK_GBS,
             "formula": "(32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B [TCC_EA0_RDREQ*] + 1024 x WRITE_SIZE) / kernel_s / 8e12; "
                        "bytes that leave the L2 are served by the Infinity Cache or by HBM",
@@ -333,7 +333,7 @@ def main():
                                                       "lds_bank_conflict_share", "l2_hit_rate") if k in dv}
             pmc["source"] = os.path.relpath(cands[-1], REPO)
         lds_scene = bool(R.scene.info("lds_scene"))
-        physical = None if stub else physical_roofline(args.scene, args.traversal, lds_scene, k_ms)
+        physical = None if stub else physical_roofline(args.scene, args.traversal, lds_scene, k_ms, passes)
         out = {
             "metric": "Msamples/sec (rays x spp x bounces = intersect() calls per second), " + wl["label"].split(" (")[0],
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

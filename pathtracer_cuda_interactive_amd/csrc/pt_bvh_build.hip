@@ -13,8 +13,8 @@
 //                       independently (one thread per node), boxes by range query — no bottom-up atomics pass
 //   PT_BVH_DEVICE_SAH   top-down, level-synchronous: every node picks, among ALL cuts of its range, the one with the
 //                       smallest surface-area cost  SA(left) * n_left + SA(right) * n_right  (one thread per cut position,
-//                       per-node argmin by 64-bit atomicMin on {cost bits, position}: deterministic); a depth cap turns
-//                       into median cuts where it binds, so the tree never outgrows the traversal stack
+//                       per-node argmin by 64-bit atomicMin on {cost bits, position}: deterministic); a depth cap of
+//                       ceil(log2 N) + 5 levels turns into median cuts where it binds (LDS stack entries cost occupancy)
 // Output: the reference's own node layout (pt_bvh_node = BVHNode, bvh.cuh:7-15) on the HOST, so that the caller can
 // hand the very same tree to pt_scene_create and to the CPU oracle.  Images on these trees are bit-identical between
 // device and oracle (tests/test_device_bvh.py); against the reference tree they differ only where two primitives tie on t.
@@ -419,7 +419,12 @@ extern "C" int pt_bvh_build_device(const pt_scene_desc* d, int method, pt_bvh_no
         HIPB(hipMemcpyAsync(d_sp.p, init.data(), (size_t)n * sizeof(SahPos), hipMemcpyHostToDevice, nullptr));
         const unsigned long long nocut = kNoCut;
         HIPB(hipMemcpyAsync(d_best.p + (n_nodes - 1), &nocut, sizeof nocut, hipMemcpyHostToDevice, nullptr));
-        const int max_depth = 48;          // leaves count 1; the traversal stack holds 64 (scene.h:251)
+        // Depth cap (leaves count 1): ceil(log2 n) + 5.  The kernel keeps one LDS stack entry per level and lane, so a
+        // deep tree takes LDS from the top-of-tree cache and, beyond ~30 levels, a resident block per CU; the cap costs
+        // little (bunny: 22.6 inner visits per segment uncapped at depth 28, 23.3 capped at 24, 32.1 at 22)
+        int lg = 0;
+        while ((1 << lg) < n) lg++;
+        const int max_depth = std::min(48, std::max(8, lg + 5));
         for (int depth = 1; depth < max_depth; depth++) {
             hipLaunchKernelGGL(sah_cost_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, d_tree.p, P, n, d_best.p);
             HIPB(hipMemsetAsync(d_misc.p + 1, 0, sizeof(int), nullptr));
