@@ -222,6 +222,14 @@ struct SahPos {
 
 constexpr unsigned long long kNoCut = ~0ull;
 
+// level 1: one node [0, n) that owns the slots [0, 2n-1)
+__global__ void sah_init_kernel(SahPos* __restrict__ pos, int n, unsigned long long* __restrict__ best) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pos[i] = SahPos{0, n, 0};
+    if (i == 0) best[2 * n - 2] = kNoCut;
+}
+
 // cost of cutting node [lo,hi) in front of position i, for every i in (lo, hi); argmin into best[root slot]
 __global__ __launch_bounds__(256) void sah_cost_kernel(const SahPos* __restrict__ pos, const Box* __restrict__ tree, int P, int n,
                                                        unsigned long long* __restrict__ best) {
@@ -387,10 +395,13 @@ extern "C" int pt_bvh_build_device(const pt_scene_desc* d, int method, pt_bvh_no
     if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
     if (method == PT_BVH_DEVICE_SAH && ((rc = d_sp.alloc(n)) || (rc = d_best.alloc(n_nodes)))) return rc;
 
-    hipEvent_t e0, e1;
-    HIPB(hipEventCreate(&e0));
-    HIPB(hipEventCreate(&e1));
-    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
+    struct EvGuard {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evg;
+    HIPB(hipEventCreate(&evg.a));
+    HIPB(hipEventCreate(&evg.b));
+    const hipEvent_t e0 = evg.a, e1 = evg.b;
     const int B = 256;
     const auto G = [&](int count) { return dim3((unsigned)((count + B - 1) / B)); };
     HIPB(hipEventRecord(e0, nullptr));
@@ -414,11 +425,7 @@ extern "C" int pt_bvh_build_device(const pt_scene_desc* d, int method, pt_bvh_no
         HIPB(hipGetLastError());
         root = n;
     } else {
-        // level 1: one node [0, n) owning slots [0, 2n-1)
-        std::vector<SahPos> init(n, SahPos{0, n, 0});
-        HIPB(hipMemcpyAsync(d_sp.p, init.data(), (size_t)n * sizeof(SahPos), hipMemcpyHostToDevice, nullptr));
-        const unsigned long long nocut = kNoCut;
-        HIPB(hipMemcpyAsync(d_best.p + (n_nodes - 1), &nocut, sizeof nocut, hipMemcpyHostToDevice, nullptr));
+        hipLaunchKernelGGL(sah_init_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, n, d_best.p);
         // Depth cap (leaves count 1): ceil(log2 n) + 5.  The kernel keeps one LDS stack entry per level and lane, so a
         // deep tree takes LDS from the top-of-tree cache and, beyond ~30 levels, a resident block per CU; the cap costs
         // little (bunny: 22.6 inner visits per segment uncapped at depth 28, 23.3 capped at 24, 32.1 at 22)
