@@ -216,6 +216,8 @@ int pt_bvh_build_device(const pt_scene_desc* desc, int method, pt_bvh_node* out_
  *                   accepted (PT_ERR_INVALID_ARG otherwise); every variant renders the same bits.
  *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
  *   "top_cache"     1 (default) scenes read from global memory keep the top levels of the BVH in LDS, 0 = all from memory
+ *   "lds_budget_kb" LDS per block for traversal stacks + that cache (0 = 31: 5 resident blocks per CU)
+ *   "chunk"         work items a wave reserves per atomic, 64..256 (0 = automatic: 128 for big launches)
  *   "xcd_regions"   0 (default) 8 row bands with XCD affinity, 1 = a single work queue
  *   "item_order"    1 (default) a band is worked through row by row (all samples of a row first), 0 = sample by sample
  *   "force_global"  1 = never stage the scene in LDS
@@ -224,7 +226,7 @@ int pt_bvh_build_device(const pt_scene_desc* desc, int method, pt_bvh_node* out_
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)
  * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables, 3 global + top of the tree in LDS), "top_nodes",
- * "passes", "occupancy", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned". */
+ * "passes", "occupancy", "blocks_per_cu", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned". */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
 int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
 

@@ -163,6 +163,22 @@ def test_top_of_tree_cache_does_not_change_the_image(oracle, dscenes, name):
     assert_bit_equal(plain, want, name + " all nodes from global memory")
     for c in (c0, c1):
         assert (c.paths, c.segments, c.node_visits, c.leaf_tests) == (cnt.paths, cnt.segments, cnt.inner_pops, cnt.leaf_tri + cnt.leaf_sphere)
+    # the LDS budget of the cache (more cached nodes, fewer resident blocks) and the work-feed chunk only move speed
+    tops = set()
+    for kb in (24, 39, 52):
+        ds.set_option("lds_budget_kb", kb)
+        try:
+            assert_bit_equal(ds.render(p), want, f"{name} lds budget {kb} KB")
+            tops.add(ds.info("top_nodes"))
+        finally:
+            ds.set_option("lds_budget_kb", 0)
+    assert len(tops) > 1
+    for chunk in (64, 128, 256):
+        ds.set_option("chunk", chunk)
+        try:
+            assert_bit_equal(ds.render(p), want, f"{name} chunk {chunk}")
+        finally:
+            ds.set_option("chunk", 0)
 
 
 @pytest.mark.parametrize("n_tris,n_spheres", [(30, 3), (44, 2), (46, 1), (47, 1), (60, 4), (170, 4), (186, 2), (196, 4), (400, 4)])
