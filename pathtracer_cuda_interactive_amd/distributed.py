@@ -24,6 +24,9 @@ def rows_of(rank, world, height):
 
 def assemble(parts, height, width, world):
     """De-interleave gathered bands [world, max_rows, W, 3] into the frame [H, W, 3]."""
+    if height % world == 0:
+        # row j = k*world + r sits at parts[r, k]: one transposing copy (one kernel on the GPU instead of `world` of them)
+        return parts.transpose(0, 1).reshape(height, width, 3)
     out = torch.empty((height, width, 3), dtype=parts.dtype, device=parts.device)
     for r in range(world):
         n = rows_of(r, world, height)

@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-from pathtracer_cuda_interactive_amd import HostScene, PT_BVH_SORT_REFERENCE, PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED
+from pathtracer_cuda_interactive_amd import HostScene, PT_BVH_SORT_REFERENCE, PT_RENDER_NEE, PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED
 from pathtracer_cuda_interactive_amd import device as dev
 
 rng = np.random.default_rng(0)
@@ -28,10 +28,14 @@ for it in range(n):
     ds.set_option("specialize", (it // 17) % 2)
     ds.set_option("top_cache", (it // 19) % 2)
     ds.set_option("item_order", (it // 23) % 2)
+    ds.set_option("chunk", [0, 64, 128, 256][(it // 29) % 4])
+    ds.set_option("lds_budget_kb", [0, 24, 39][(it // 31) % 3])
+    nee = kernel == 2 and (it // 37) % 2 == 1
     p = hs.render_params(w, h, spp)
+    p.flags = PT_RENDER_NEE if nee else 0
     p.row_begin, p.row_end, p.row_stride = it % stride, h, stride
     img = ds.render(p, traversal=trav)
-    key = (name, w, h, spp, p.row_begin, stride)
+    key = (name, w, h, spp, p.row_begin, stride, nee)
     if key not in ref:
         ref[key] = img
     elif not (ref[key].view(np.uint32) == img.view(np.uint32)).all():
