@@ -3,7 +3,8 @@
 //
 //   build: g++ -std=c++17 -O2 -Iinclude examples/render_main.cpp -Lpathtracer_cuda_interactive_amd -lpt_host -lpt_hip \
 //              -Wl,-rpath,'$ORIGIN/../pathtracer_cuda_interactive_amd' -o examples/render_main
-//   run  : examples/render_main scene.xml|scene.pts out.pfm [width height spp]
+//   run  : examples/render_main scene.xml|scene.pts out.pfm [width height spp [reference|lbvh|sah [nee]]]
+//          (the last two are the extensions of include/pt_api.h: BVH built on the GPU, next-event estimation)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +21,7 @@ static double now() {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s scene.xml|scene.pts out.pfm|out.ppm [width height spp]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s scene.xml|scene.pts out.pfm|out.ppm [width height spp [reference|lbvh|sah [nee]]]\n", argv[0]);
         return 2;
     }
     const std::string path = argv[1], out = argv[2];
@@ -40,7 +41,24 @@ int main(int argc, char** argv) {
     const int W = argc > 3 ? std::atoi(argv[3]) : cam.width;
     const int H = argc > 4 ? std::atoi(argv[4]) : cam.height;
     const int spp = argc > 5 ? std::atoi(argv[5]) : cam.spp;
-    std::printf("Maximum BVH depth: %d\n", pt_host_scene_bvh_depth(hs));                                           // scene.cpp:148-149
+    const std::string tree = argc > 6 ? argv[6] : "reference";
+    const bool nee = argc > 7 && std::strcmp(argv[7], "nee") == 0;
+    std::vector<pt_bvh_node> device_nodes;
+    int depth = pt_host_scene_bvh_depth(hs);
+    if (tree == "lbvh" || tree == "sah") {                // construct_bvh (bvh.cu:16-54) replaced by the device builder
+        device_nodes.resize(2 * size_t(desc.num_shapes) - 1);
+        int32_t root = 0, d = 0;
+        double build_ms = 0;
+        rc = pt_bvh_build_device(&desc, tree == "sah" ? PT_BVH_DEVICE_SAH : PT_BVH_DEVICE_LBVH, device_nodes.data(), &root, &d, &build_ms);
+        if (rc != PT_OK) { std::fprintf(stderr, "device BVH build failed (%d): %s\n", rc, pt_last_error()); return 1; }
+        desc.nodes = device_nodes.data(); desc.num_nodes = int32_t(device_nodes.size()); desc.root = root;
+        depth = d;
+        std::printf("device %s build: %.2f ms\n", tree.c_str(), build_ms);
+    } else if (tree != "reference") {
+        std::fprintf(stderr, "unknown tree '%s'\n", tree.c_str());
+        return 2;
+    }
+    std::printf("Maximum BVH depth: %d\n", depth);                                                                 // scene.cpp:148-149
     const double t1 = now();
 
     pt_scene* scene = nullptr;
@@ -50,6 +68,7 @@ int main(int argc, char** argv) {
     }
     pt_render_params rp;
     pt_host_default_params(&cam, W, H, spp, &rp);                                                                   // main.cu:237 + constants
+    if (nee) rp.flags = PT_RENDER_NEE;
     std::vector<float> fb(size_t(W) * H * 3);
     const double t2 = now();
     if ((rc = pt_render(scene, &rp, fb.data(), 0)) != PT_OK) {                                                      // main.cu:234,258-260

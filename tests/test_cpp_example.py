@@ -33,3 +33,21 @@ def test_example_renders_the_oracle_image(oracle, binary, tmp_path, name):
     hs, d = load_scene(name)
     want, _ = oracle.render(d, hs.render_params(48, 36, 5))
     assert_bit_equal(read_pfm(out), want, name)
+
+
+@pytest.mark.gpu
+def test_example_with_device_tree_and_nee(oracle, binary, tmp_path):
+    """The two extensions through the bare C ABI: the tree built on the GPU, next-event estimation.  The oracle renders on
+    the same device-built tree (the builder is deterministic, so the Python binding gets the very same nodes)."""
+    from pathtracer_cuda_interactive_amd import PT_RENDER_NEE
+    from pathtracer_cuda_interactive_amd import device as dev
+    out = tmp_path / "frame.pfm"
+    r = subprocess.run([binary, f"{SCENES}/teapot.pts", str(out), "48", "36", "4", "sah", "nee"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "device sah build" in r.stdout
+    hs, d = load_scene("teapot")
+    d2, _ = dev.build_bvh_device(d, dev.PT_BVH_DEVICE_SAH)
+    p = hs.render_params(48, 36, 4)
+    p.flags = PT_RENDER_NEE
+    want, _ = oracle.render(d2, p)
+    assert_bit_equal(read_pfm(out), want, "teapot, device SAH tree, NEE")
