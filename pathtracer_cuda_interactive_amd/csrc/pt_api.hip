@@ -82,13 +82,16 @@ constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node 
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
 constexpr uint64_t kDefaultScratchBytes = 8ull << 30;   // per-sample scratch cap (3 % of the 288 GB of HBM): every sample pass
                                                         // pays the launch floor once (buddha stand-in 135.6 ms in 5 passes, 130.6 in 1)
-constexpr uint32_t kTopNodes = 512;              // scenes read from global memory: this many nodes are numbered breadth-first
+#ifndef PT_TOP_NODES
+#define PT_TOP_NODES 512
+#endif
+constexpr uint32_t kTopNodes = PT_TOP_NODES;              // scenes read from global memory: this many nodes are numbered breadth-first
                                                  // from the root, so that [0, k) is the top of the tree for every k (LDS cache)
 #ifndef PT_TOP_LDS_KB
 #define PT_TOP_LDS_KB 31
 #endif
 constexpr uint32_t kTopLdsBudget = PT_TOP_LDS_KB * 1024;    // LDS per block that keeps 5 blocks per CU resident (160 KB / 5, minus slack)
-constexpr uint32_t kMaxLdsBudget = 64 * 1024;               // the breadth-first numbered prefix is sized for the largest budget an option may ask for
+constexpr uint32_t kMaxLdsBudget = 160 * 1024;               // the breadth-first numbered prefix is sized for the largest budget an option may ask for
 constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band counters, one 128-B line each
 constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
 

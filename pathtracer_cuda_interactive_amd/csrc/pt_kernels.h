@@ -20,7 +20,10 @@ namespace ptk {
 using namespace ptl;
 
 
-constexpr int kBlock = 256;          // 4 waves
+#ifndef PT_BLOCK
+#define PT_BLOCK 256
+#endif
+constexpr int kBlock = PT_BLOCK;     // 4 waves (PT_BLOCK: block-size experiments)
 constexpr uint32_t kMaxChunk = 256;  // most work items a wave reserves per atomic (RenderDev::chunk)
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(SceneDev scn, RenderDev r
 // NEE = built with next-event estimation (PT_RENDER_NEE): a lane alternates between closest-hit traversals and the
 // any-hit traversal of its light sample's shadow ray; the same step functions serve both.
 template <int RES, bool PRUNE, bool STATS, int THRESH, int INNER, int MINW, int SPEC, bool NEE = false>
-__global__ __launch_bounds__(kBlock, MINW) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
+__global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kernel_v2(SceneDev scn, RenderDev rp, LdsPlan lp,
                                                           float4* __restrict__ samples,
                                                           uint32_t* __restrict__ work_counter,
                                                           unsigned long long* __restrict__ counters) {
