@@ -21,7 +21,11 @@ import oracle_binding as ob  # noqa: E402
 from pathtracer_cuda_interactive_amd import HostScene, PT_BVH_SORT_REFERENCE  # noqa: E402
 
 IMAGES = {"scene1": (64, 48, 4), "scene1_phong": (64, 48, 4), "cbox": (64, 48, 4), "teapot": (48, 48, 2),
-          "bunny": (64, 48, 1), "tetrahedron": (48, 48, 4)}
+          "bunny": (64, 48, 1), "tetrahedron": (48, 48, 4),
+          # the rest of the scenes the reference ships (dragon / buddha need meshes that are missing from the snapshot)
+          "scene0": (48, 48, 4), "scene0_spherical_light": (64, 48, 4), "scene1_spherical_light": (64, 48, 4),
+          "scene2": (64, 48, 4), "scene3": (64, 48, 4), "scene4": (64, 48, 4), "aabb_test": (64, 48, 2),
+          "single_triangle": (64, 48, 2)}
 N_RAYS = 1024
 
 
@@ -69,7 +73,7 @@ if __name__ == "__main__":
                       "lights": d.num_lights, "nodes": d.num_nodes, "root": d.root, "depth": hs.bvh_depth}
         print(name, topo[name], "segments", cnt.segments, "hits", int((prim >= 0).sum()), "/", len(prim))
     pins = {
-        "_source": "SURVEY.md §8c (values recorded from a host build of the reference's own headers) + topology from this build",
+        "_source": "SURVEY.md §8c (values recorded from a host build of the reference's own headers) + the published pcg32 demo vector + topology from this build",
         "pcg": [
             {"stream": 1, "seed": 0x853c49e6748fea9b, "state": 0xf6e7b88658a69fc9, "inc": 0x3,
              "u32": [0x73c29fdb, 0xfbaa1ff7, 0xdb022af6, 0x12d7398c]},
@@ -78,6 +82,9 @@ if __name__ == "__main__":
              "f32": [0.700181603, 0.728500009, 0.210561395, 0.909029841]},
             {"stream": 307199, "seed": 1984, "state": 0x73fb18ddc2535d92, "inc": 0x95fff,
              "u32": [0x1181fd82, 0xfc486444, 0x250ed378, 0x594aa51b]},
+            {"stream": 54, "seed": 42, "u32": [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e],
+             "published": "pcg32-demo of the PCG reference implementation (pcg-c-basic): pcg32_srandom_r(&rng, 42u, 54u) -> first "
+                          "six 32-bit outputs; independent of this repo and of the reference"},
         ],
         "survey_images_libm_per_pixel_rng": {
             "scene1": {"w": 640, "h": 480, "spp": 16, "mean": 0.325954931, "max": 1.67586458,
@@ -94,6 +101,7 @@ if __name__ == "__main__":
             "cbox": {"shapes": 38, "meshes": 8, "materials": 5, "lights": 2, "nodes": 75, "root": 74, "depth": 7},
             "bunny": {"shapes": 288094, "meshes": 3, "nodes": 576187, "depth": 20},
             "teapot": {"shapes": 15706, "nodes": 31411, "depth": 15},
+            "scene4": {"shapes": 30, "nodes": 59, "depth": 6},
         },
         "topology": topo,
     }

@@ -13,6 +13,13 @@ SCENES = {
     "scene1": "spheres/scene1.xml",
     "scene1_phong": "spheres/scene1_spherical_light_phong.xml",
     "scene4": "spheres/scene4.xml",
+    "scene0": "spheres/scene0.xml",
+    "scene0_spherical_light": "spheres/scene0_spherical_light.xml",
+    "scene1_spherical_light": "spheres/scene1_spherical_light.xml",
+    "scene2": "spheres/scene2.xml",
+    "scene3": "spheres/scene3.xml",
+    "aabb_test": "aabb_test/aabb_test.xml",
+    "single_triangle": "triangles/single_triangle.xml",
     "cbox": "cbox/cbox.xml",
     "bunny": "bunny/bunny.xml",
     "teapot": "teapot/teapot_constant.xml",
