@@ -80,6 +80,7 @@ struct DeviceGuard {
 constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
 constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node table must fit in this many bytes of LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
+constexpr int kProbeRays = 32768;                // validate_and_build: rays that choose between the caller's tree and the internal one
 constexpr uint64_t kDefaultScratchBytes = 8ull << 30;   // per-sample scratch cap (3 % of the 288 GB of HBM): every sample pass
                                                         // pays the launch floor once (buddha stand-in 135.6 ms in 5 passes, 130.6 in 1)
 #ifndef PT_TOP_NODES
@@ -103,9 +104,19 @@ struct pt_scene {
     int device = 0;
     int num_cus = 0;
     size_t lds_per_block_max = 0;
-    // scene arrays
-    DevBuf<DNode> nodes;
-    DevBuf<DNode> nodes_oct;         // [8][num_nodes] octant-specialised copies (small scenes only)
+    // scene arrays.  Two layouts of the hierarchy: tree[0] = the caller's tree (the reference's, bvh.cu:16-54), tree[1] = a
+    // surface-area-cost tree over the SAME leaf boxes built on the device at create time (pt_bvh_build.hip).  Exact traversal
+    // runs on tree[1] and falls back to tree[0] for the rays whose result depends on the visit order (see launch_render).
+    struct Tree {
+        DevBuf<DNode> nodes;
+        DevBuf<DNode> nodes_oct;     // [8][num_nodes] octant-specialised copies (small scenes only)
+        bool have_oct = false;
+        int32_t num_nodes = 0, root_ref = 0, stack_cap = 0;
+        uint32_t top_avail = 0;      // nodes [0, top_avail) are the top of the tree in breadth-first order (0 = plain pre-order)
+        int depth = 0;
+    } tree[2];
+    bool have_fast = false;
+    DevBuf<int32_t> redo_stack;      // global-memory traversal stacks of the reference-order reruns (one column per lane of the grid)
     DevBuf<DPrim> prims;
     DevBuf<DNormals> normals;
     DevBuf<DMaterial> materials;
@@ -115,8 +126,6 @@ struct pt_scene {
     uint32_t scene_bytes = 0;
     bool tri_only = false;           // the scene holds no sphere
     bool diffuse_only = false;       // every material is DIFFUSE
-    uint32_t top_avail = 0;          // nodes [0, top_avail) are the top of the tree in breadth-first order (0 = plain pre-order)
-    int bvh_depth = 0;
     // scratch
     DevBuf<float4> samples;
     DevBuf<float> accum;
@@ -135,6 +144,7 @@ struct pt_scene {
     int64_t opt_specialize = 1;      // compile-time specialisation on scene content (no spheres -> sphere code removed)
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
+    int64_t opt_fast_tree = 1;       // exact traversal on the internal surface-area-cost tree with reference-order reruns (0 = on the caller's tree)
     int64_t opt_chunk = 0;           // work items a wave reserves per atomic (0 = automatic)
     int64_t opt_lds_budget_kb = 0;   // scenes in global memory: LDS per block for traversal stacks + top-of-tree cache (0 = 31 KB: 5 blocks per CU)
     int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
@@ -142,7 +152,7 @@ struct pt_scene {
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
     // info of last launch
-    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0;
+    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0, info_debug_reruns = 0, fast_cost_permille = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
     std::vector<PassEvents> pass_events;                         // pool, reused from frame to frame
     size_t passes_timed = 0;                                     // events of the last frame: pass_events[0 .. passes_timed)
@@ -158,6 +168,128 @@ struct pt_scene {
 };
 
 namespace {
+
+// Points the kernel argument block at one of the two layouts; fallback: exact traversal on the internal tree reruns the rays
+// whose result depends on the visit order on tree[0].
+void select_tree(pt_scene* S, int which, bool fallback = false) {
+    const pt_scene::Tree& T = S->tree[which];
+    SceneDev& dv = S->dev;
+    dv.nodes = T.nodes.p;
+    dv.nodes_oct = T.have_oct ? T.nodes_oct.p : nullptr;
+    dv.num_nodes = T.num_nodes;
+    dv.root_ref = T.root_ref;
+    dv.stack_cap = T.stack_cap;
+    dv.fallback = fallback ? 1 : 0;
+    dv.ref_nodes = S->tree[0].nodes.p;
+    dv.ref_root_ref = S->tree[0].root_ref;
+    dv.redo_cap = S->tree[0].stack_cap;
+    dv.redo_stack = S->redo_stack.p;
+}
+
+struct TreeHost {
+    std::vector<DNode> nodes;
+    int32_t root_ref = 0;
+    int depth = 1;
+    uint32_t top_avail = 0;
+};
+
+// pt_bvh_node pool (one node per leaf and per inner node, bvh.cuh:7-15) -> inner-only DNodes carrying both child boxes.
+// Validates the topology.  leaf_boxes (optional, [N][6]): receives every primitive's leaf box.  *nested: every node's box
+// below the root contains its children's boxes.
+int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost& out, float* leaf_boxes, bool* nested) {
+    std::vector<int32_t> inner_id(num_nodes, -1);
+    std::vector<DNode>& nodes = out.nodes;
+    nodes.clear();
+    nodes.reserve(N > 1 ? N - 1 : 1);
+    int depth = 1;
+    std::vector<char> prim_seen(N, 0);
+    auto leaf_ok = [&](const pt_bvh_node& nd) { return nd.prim >= 0 && nd.prim < N; };
+    auto contains = [](const pt_bvh_node& outer, const pt_bvh_node& inner) {
+        for (int k = 0; k < 3; k++)
+            if (!(inner.bmin[k] >= outer.bmin[k] && inner.bmax[k] <= outer.bmax[k])) return false;
+        return true;
+    };
+    const pt_bvh_node& rootn = in[root];
+    if (rootn.prim != -1) {
+        if (!leaf_ok(rootn)) return fail(PT_ERR_BAD_SCENE, "leaf primitive id out of range");
+        out.root_ref = ~rootn.prim;
+        prim_seen[rootn.prim] = 1;
+        if (leaf_boxes) { std::memcpy(leaf_boxes + 6 * (size_t)rootn.prim, rootn.bmin, 12); std::memcpy(leaf_boxes + 6 * (size_t)rootn.prim + 3, rootn.bmax, 12); }
+    } else {
+        // DFS pre-order: a parent and its left subtree are contiguous in memory
+        struct Item { int32_t ref_node; int depth; };
+        std::vector<Item> todo;
+        todo.push_back({root, 1});
+        size_t visited = 0;
+        std::vector<int32_t> order;
+        while (!todo.empty()) {
+            Item it = todo.back();
+            todo.pop_back();
+            const pt_bvh_node& nd = in[it.ref_node];
+            if (++visited > (size_t)num_nodes) return fail(PT_ERR_BAD_SCENE, "BVH is not a tree (cycle)");
+            if (inner_id[it.ref_node] != -1) return fail(PT_ERR_BAD_SCENE, "BVH node referenced twice");
+            if (nd.left < 0 || nd.left >= num_nodes || nd.right < 0 || nd.right >= num_nodes)
+                return fail(PT_ERR_BAD_SCENE, "BVH child index out of range");
+            inner_id[it.ref_node] = (int32_t)order.size();
+            order.push_back(it.ref_node);
+            if (it.depth + 1 > depth) depth = it.depth + 1;
+            const pt_bvh_node& ln = in[nd.left];
+            const pt_bvh_node& rn = in[nd.right];
+            if (it.ref_node != root && nested && !(contains(nd, ln) && contains(nd, rn))) *nested = false;
+            if (rn.prim == -1) todo.push_back({nd.right, it.depth + 1});
+            if (ln.prim == -1) todo.push_back({nd.left, it.depth + 1});
+        }
+        // Scenes too big for LDS: renumber so that the first kTopNodes ids are the top of the tree in breadth-first order
+        // (every ray starts there; the kernel keeps a prefix of them in LDS), the rest stays in pre-order.
+        if ((size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + order.size() * sizeof(DNode) > kLdsSceneLimit && order.size() > 1) {
+            // only as many as fit next to the traversal stacks (make_plan)
+            const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)(std::max(depth - 1, 1) + 1) * 64u * 4u;
+            const size_t want = std::min<size_t>(kTopNodes, kMaxLdsBudget > stack_bytes ? (kMaxLdsBudget - stack_bytes) / sizeof(DNode) : 0);
+            std::vector<int32_t> top;
+            std::vector<char> in_top(num_nodes, 0);
+            if (want) top.push_back(root);
+            for (size_t head = 0; head < top.size() && top.size() < want; head++) {
+                const pt_bvh_node& nd = in[top[head]];
+                for (int32_t ch : {nd.left, nd.right})
+                    if (in[ch].prim == -1 && top.size() < want) top.push_back(ch);
+            }
+            for (int32_t r : top) in_top[r] = 1;
+            std::vector<int32_t> renum(top);
+            for (int32_t r : order)
+                if (!in_top[r]) renum.push_back(r);
+            order.swap(renum);
+            for (size_t k = 0; k < order.size(); k++) inner_id[order[k]] = (int32_t)k;
+            out.top_avail = (uint32_t)top.size();
+        }
+        nodes.resize(order.size());
+        for (size_t k = 0; k < order.size(); k++) {
+            const pt_bvh_node& nd = in[order[k]];
+            const pt_bvh_node& ln = in[nd.left];
+            const pt_bvh_node& rn = in[nd.right];
+            DNode& o = nodes[k];
+            std::memcpy(o.lmin, ln.bmin, 12); std::memcpy(o.lmax, ln.bmax, 12);
+            std::memcpy(o.rmin, rn.bmin, 12); std::memcpy(o.rmax, rn.bmax, 12);
+            for (const pt_bvh_node* ch : {&ln, &rn})
+                if (ch->prim != -1) {
+                    if (!leaf_ok(*ch)) return fail(PT_ERR_BAD_SCENE, "leaf primitive id out of range");
+                    if (prim_seen[ch->prim]) return fail(PT_ERR_BAD_SCENE, "primitive referenced by two leaves");
+                    prim_seen[ch->prim] = 1;
+                    if (leaf_boxes) { std::memcpy(leaf_boxes + 6 * (size_t)ch->prim, ch->bmin, 12); std::memcpy(leaf_boxes + 6 * (size_t)ch->prim + 3, ch->bmax, 12); }
+                }
+            o.left = ln.prim != -1 ? ~ln.prim : inner_id[nd.left];
+            o.right = rn.prim != -1 ? ~rn.prim : inner_id[nd.right];
+            o.pad0 = o.pad1 = 0;
+        }
+        out.root_ref = 0;
+    }
+    for (int i = 0; i < N; i++)
+        if (!prim_seen[i]) return fail(PT_ERR_BAD_SCENE, "primitive not covered by any leaf");
+    if (depth - 1 > kMaxStack - 1)
+        return fail(PT_ERR_BAD_SCENE, "BVH deeper than the traversal stack (reference cap 64, scene.h:251)");
+    out.depth = depth;
+    if (nodes.empty()) nodes.resize(1);   // single-primitive scene: no inner nodes; keep a dummy so pointers are valid
+    return PT_OK;
+}
 
 int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     if (!d) return fail(PT_ERR_INVALID_ARG, "null scene description");
@@ -219,88 +351,33 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     for (int i = 0; i < N; i++)
         if (d->shapes[i].type == PT_SHAPE_SPHERE) { S->tri_only = false; break; }
 
-    // ---- BVH: reference node pool -> inner-only nodes carrying both child boxes
-    std::vector<int32_t> inner_id(d->num_nodes, -1);
-    std::vector<DNode> nodes;
-    nodes.reserve(N > 1 ? N - 1 : 1);
-    int depth = 1;
-    int32_t root_ref;
-    std::vector<char> prim_seen(N, 0);
-    auto leaf_ok = [&](const pt_bvh_node& nd) { return nd.prim >= 0 && nd.prim < N; };
-    const pt_bvh_node& rootn = d->nodes[d->root];
-    if (rootn.prim != -1) {
-        if (!leaf_ok(rootn)) return fail(PT_ERR_BAD_SCENE, "leaf primitive id out of range");
-        root_ref = ~rootn.prim;
-        prim_seen[rootn.prim] = 1;
-    } else {
-        // DFS pre-order: a parent and its left subtree are contiguous in memory
-        struct Item { int32_t ref_node; int depth; };
-        std::vector<Item> todo;
-        todo.push_back({d->root, 1});
-        size_t visited = 0;
-        // first pass: assign ids in pre-order
-        std::vector<int32_t> order;
-        while (!todo.empty()) {
-            Item it = todo.back();
-            todo.pop_back();
-            const pt_bvh_node& nd = d->nodes[it.ref_node];
-            if (++visited > (size_t)d->num_nodes) return fail(PT_ERR_BAD_SCENE, "BVH is not a tree (cycle)");
-            if (inner_id[it.ref_node] != -1) return fail(PT_ERR_BAD_SCENE, "BVH node referenced twice");
-            if (nd.left < 0 || nd.left >= d->num_nodes || nd.right < 0 || nd.right >= d->num_nodes)
-                return fail(PT_ERR_BAD_SCENE, "BVH child index out of range");
-            inner_id[it.ref_node] = (int32_t)order.size();
-            order.push_back(it.ref_node);
-            if (it.depth + 1 > depth) depth = it.depth + 1;
-            const pt_bvh_node& ln = d->nodes[nd.left];
-            const pt_bvh_node& rn = d->nodes[nd.right];
-            if (rn.prim == -1) todo.push_back({nd.right, it.depth + 1});
-            if (ln.prim == -1) todo.push_back({nd.left, it.depth + 1});
+    // ---- BVH: the caller's tree (validated), and the internal tree over the same leaf boxes
+    TreeHost ref;
+    std::vector<float> leaf_boxes((size_t)N * 6);
+    bool nested = true;
+    int trc = convert_tree(d->nodes, d->num_nodes, d->root, N, ref, leaf_boxes.data(), &nested);
+    if (trc) return trc;
+    TreeHost fast;
+    bool have_fast = false;
+    const bool small_scene = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref.nodes.size() * sizeof(DNode) + 1024 <= kLdsSceneLimit / 2;
+    if (N >= 2 && nested && !small_scene) {        // (scenes far below the LDS limit never leave LDS: no second tree for them)
+        // A leaf is tested by the reference iff the ray hits every box on its way down (scene.h:278-297, no pruning).  The slab
+        // test is monotone in the box (rounding is), so where every box contains its children's that is: iff it hits the LEAF's
+        // own box — whatever the tree above it.  `nested` says the caller's tree is of that kind; then any tree over the same
+        // leaf boxes tests the same leaves, and only the ORDER of the tests (ties on t, scene.h:270) still depends on the tree.
+        std::vector<pt_bvh_node> fnodes((size_t)d->num_nodes);
+        int froot = 0, fdepth = 0;
+        // LDS-resident scenes: one level more than the caller's tree at most, so that the traversal stacks keep their size
+        // (cbox: 26.5 KB per block = 6 resident blocks; one more stack entry pair would cost a block per CU).  Larger scenes:
+        // the builder's default of ceil(log2 N) + 5 levels.
+        const bool small = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref.nodes.size() * sizeof(DNode) <= kLdsSceneLimit;
+        const int cap = small ? ref.depth + 1 : 0;      // (used only with force_global)
+        if (pt_bvh_build_from_boxes(leaf_boxes.data(), N, PT_BVH_DEVICE_SAH, fnodes.data(), &froot, &fdepth, cap) == PT_OK) {
+            bool fnested = true;
+            have_fast = convert_tree(fnodes.data(), d->num_nodes, froot, N, fast, nullptr, &fnested) == PT_OK && fnested;
         }
-        // Scenes too big for LDS: renumber so that the first kTopNodes ids are the top of the tree in breadth-first order
-        // (every ray starts there; the kernel keeps a prefix of them in LDS), the rest stays in pre-order.
-        if ((size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + order.size() * sizeof(DNode) > kLdsSceneLimit && order.size() > 1) {
-            // only as many as fit next to the traversal stacks (make_plan)
-            const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)(std::max(depth - 1, 1) + 1) * 64u * 4u;
-            const size_t want = std::min<size_t>(kTopNodes, kMaxLdsBudget > stack_bytes ? (kMaxLdsBudget - stack_bytes) / sizeof(DNode) : 0);
-            std::vector<int32_t> top;
-            std::vector<char> in_top(d->num_nodes, 0);
-            if (want) top.push_back(d->root);
-            for (size_t head = 0; head < top.size() && top.size() < want; head++) {
-                const pt_bvh_node& nd = d->nodes[top[head]];
-                for (int32_t ch : {nd.left, nd.right})
-                    if (d->nodes[ch].prim == -1 && top.size() < want) top.push_back(ch);
-            }
-            for (int32_t r : top) in_top[r] = 1;
-            std::vector<int32_t> renum(top);
-            for (int32_t r : order)
-                if (!in_top[r]) renum.push_back(r);
-            order.swap(renum);
-            for (size_t k = 0; k < order.size(); k++) inner_id[order[k]] = (int32_t)k;
-            S->top_avail = (uint32_t)top.size();
-        }
-        nodes.resize(order.size());
-        for (size_t k = 0; k < order.size(); k++) {
-            const pt_bvh_node& nd = d->nodes[order[k]];
-            const pt_bvh_node& ln = d->nodes[nd.left];
-            const pt_bvh_node& rn = d->nodes[nd.right];
-            DNode& o = nodes[k];
-            std::memcpy(o.lmin, ln.bmin, 12); std::memcpy(o.lmax, ln.bmax, 12);
-            std::memcpy(o.rmin, rn.bmin, 12); std::memcpy(o.rmax, rn.bmax, 12);
-            for (const pt_bvh_node* ch : {&ln, &rn})
-                if (ch->prim != -1) {
-                    if (!leaf_ok(*ch)) return fail(PT_ERR_BAD_SCENE, "leaf primitive id out of range");
-                    if (prim_seen[ch->prim]) return fail(PT_ERR_BAD_SCENE, "primitive referenced by two leaves");
-                    prim_seen[ch->prim] = 1;
-                }
-            o.left = ln.prim != -1 ? ~ln.prim : inner_id[nd.left];
-            o.right = rn.prim != -1 ? ~rn.prim : inner_id[nd.right];
-            o.pad0 = o.pad1 = 0;
-        }
-        root_ref = 0;
     }
-    if (depth - 1 > kMaxStack - 1)
-        return fail(PT_ERR_BAD_SCENE, "BVH deeper than the traversal stack (reference cap 64, scene.h:251)");
-
+    const TreeHost* hosts[2] = {&ref, have_fast ? &fast : nullptr};
     std::vector<DMaterial> mats(d->num_materials);
     for (int m = 0; m < d->num_materials; m++) {
         const pt_material& src = d->materials[m];
@@ -321,78 +398,111 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         if (src.type == PT_LIGHT_DIFFUSE_AREA && (src.shape_id < 0 || src.shape_id >= N))
             return fail(PT_ERR_BAD_SCENE, "area light refers to a shape that does not exist");
     }
-    if (nodes.empty()) nodes.resize(1);   // single-primitive scene: no inner nodes; keep a dummy so pointers are valid
-
     int rc;
-    // 8 ray-octant copies of the node table for LDS-resident scenes: octant bit k set <=> 1/d[k] < 0, in which case
-    // Hit() swaps the two slab distances of axis k (bbox.cuh:40-55); here the two planes are swapped instead.
-    std::vector<DNode> nodes_oct;
-    if (nodes.size() * 8 * sizeof(DNode) <= kOctNodeLimit) {
-        nodes_oct.resize(nodes.size() * 8);
-        for (int o = 0; o < 8; o++)
-            for (size_t k = 0; k < nodes.size(); k++) {
-                DNode n = nodes[k];
-                for (int ax = 0; ax < 3; ax++)
-                    if (o & (1 << ax)) { std::swap(n.lmin[ax], n.lmax[ax]); std::swap(n.rmin[ax], n.rmax[ax]); }
-                nodes_oct[(size_t)o * nodes.size() + k] = n;
-            }
-        if ((rc = S->nodes_oct.ensure(nodes_oct.size()))) return rc;
-        HIP_TRY(hipMemcpy(S->nodes_oct.p, nodes_oct.data(), nodes_oct.size() * sizeof(DNode), hipMemcpyHostToDevice));
+    for (int t = 0; t < 2; t++) {
+        if (!hosts[t]) continue;
+        const std::vector<DNode>& nodes = hosts[t]->nodes;
+        pt_scene::Tree& T = S->tree[t];
+        // 8 ray-octant copies of the node table for LDS-resident scenes: octant bit k set <=> 1/d[k] < 0, in which case
+        // Hit() swaps the two slab distances of axis k (bbox.cuh:40-55); here the two planes are swapped instead.
+        if (nodes.size() * 8 * sizeof(DNode) <= kOctNodeLimit) {
+            std::vector<DNode> nodes_oct(nodes.size() * 8);
+            for (int o = 0; o < 8; o++)
+                for (size_t k = 0; k < nodes.size(); k++) {
+                    DNode n = nodes[k];
+                    for (int ax = 0; ax < 3; ax++)
+                        if (o & (1 << ax)) { std::swap(n.lmin[ax], n.lmax[ax]); std::swap(n.rmin[ax], n.rmax[ax]); }
+                    nodes_oct[(size_t)o * nodes.size() + k] = n;
+                }
+            if ((rc = T.nodes_oct.ensure(nodes_oct.size()))) return rc;
+            HIP_TRY(hipMemcpy(T.nodes_oct.p, nodes_oct.data(), nodes_oct.size() * sizeof(DNode), hipMemcpyHostToDevice));
+            T.have_oct = true;
+        }
+        if ((rc = T.nodes.ensure(nodes.size()))) return rc;
+        HIP_TRY(hipMemcpy(T.nodes.p, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
+        T.num_nodes = (int32_t)nodes.size();
+        T.root_ref = hosts[t]->root_ref;
+        T.stack_cap = std::max(hosts[t]->depth - 1, 1) + 1;     // + the kDone sentinel at the bottom
+        T.top_avail = hosts[t]->top_avail;
+        T.depth = hosts[t]->depth;
     }
-    if ((rc = S->nodes.ensure(nodes.size()))) return rc;
+    S->have_fast = have_fast;
     if ((rc = S->prims.ensure(prims.size()))) return rc;
     if ((rc = S->normals.ensure(normals.size()))) return rc;
     if ((rc = S->materials.ensure(mats.size()))) return rc;
     if ((rc = S->emission.ensure(emis.size()))) return rc;
     if ((rc = S->lights.ensure(dlights.size()))) return rc;
     HIP_TRY(hipMemcpy(S->lights.p, dlights.data(), dlights.size() * sizeof(DLight), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S->nodes.p, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->prims.p, prims.data(), prims.size() * sizeof(DPrim), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->normals.p, normals.data(), normals.size() * sizeof(DNormals), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->materials.p, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->emission.p, emis.data(), emis.size() * sizeof(DEmission), hipMemcpyHostToDevice));
 
     SceneDev& dv = S->dev;
-    dv.nodes = S->nodes.p; dv.nodes_oct = nodes_oct.empty() ? nullptr : S->nodes_oct.p; dv.prims = S->prims.p; dv.normals = S->normals.p;
+    dv.prims = S->prims.p; dv.normals = S->normals.p;
     dv.materials = S->materials.p; dv.emission = S->emission.p; dv.lights = S->lights.p;
-    dv.num_nodes = (int32_t)nodes.size();
     dv.num_prims = N;
     dv.num_materials = d->num_materials;
     dv.num_emission = d->num_lights;
-    dv.root_ref = root_ref;
-    dv.stack_cap = std::max(depth - 1, 1) + 1;     // + the kDone sentinel at the bottom
     dv.bg[0] = d->background[0]; dv.bg[1] = d->background[1]; dv.bg[2] = d->background[2];
-    S->bvh_depth = depth;
+    // Keep the internal tree only where it is the better one FOR THIS KIND OF RAY: without pruning a node is visited iff the
+    // ray hits its box, and what the boxes of a tree add up to depends on the scene (a soup of large overlapping triangles is
+    // better off with the caller's median splits than with cuts of the Morton order; a far-away ground sphere skews any
+    // surface-area estimate).  So measure: the same probe rays — from random points on the primitives into uniform
+    // directions, which is where and how the segments after the first bounce start — through both trees, inner visits counted.
+    S->fast_cost_permille = 0;
+    if (have_fast) {
+        DevBuf<unsigned long long> visits;
+        if ((rc = visits.ensure(2))) return rc;
+        HIP_TRY(hipMemset(visits.p, 0, 2 * sizeof(unsigned long long)));
+        for (int t = 0; t < 2; t++) {
+            select_tree(S, t);
+            const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
+            hipLaunchKernelGGL(probe_kernel, dim3(kProbeRays / kBlock), dim3(kBlock), lds, nullptr, S->dev, visits.p + t);
+            HIP_TRY(hipGetLastError());
+        }
+        unsigned long long v[2] = {0, 0};
+        HIP_TRY(hipMemcpy(v, visits.p, sizeof(v), hipMemcpyDeviceToHost));
+        S->fast_cost_permille = v[0] ? (int64_t)((1000ull * v[1] + v[0] / 2) / v[0]) : 1000;
+        if (!(v[1] * 100ull < v[0] * 90ull)) {              // not at least 10 % fewer boxes: not worth a second tree
+            S->have_fast = false;
+            S->tree[1].nodes.release();
+            S->tree[1].nodes_oct.release();
+            S->tree[1].have_oct = false;
+        }
+    }
+    select_tree(S, 0);
     S->scene_bytes = (uint32_t)std::min<size_t>(
-        nodes.size() * sizeof(DNode) + prims.size() * (sizeof(DPrim) + sizeof(DNormals)) + mats.size() * sizeof(DMaterial) +
+        ref.nodes.size() * sizeof(DNode) + prims.size() * (sizeof(DPrim) + sizeof(DNormals)) + mats.size() * sizeof(DMaterial) +
             emis.size() * sizeof(DEmission) + 64, 0xffffffffu);
     return PT_OK;
 }
 
 // res: 0 scene in global memory, 1 scene staged in LDS, 2 staged in LDS with the 8 octant node tables,
 //      3 scene in global memory with the top of the tree cached in LDS
-LdsPlan make_plan(const pt_scene* S, int res, bool stack16) {
+LdsPlan make_plan(const pt_scene* S, int res, bool stack16, int which = 0) {
     LdsPlan lp{};
+    const pt_scene::Tree& T = S->tree[which];
     uint32_t off = 0;
     if (res == 3) {
         // as many top nodes as fit next to the stacks within the block's LDS budget (default: without costing a resident block)
-        const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
+        const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)T.stack_cap * 64u * 4u;
         const uint32_t budget = S->opt_lds_budget_kb > 0 ? (uint32_t)S->opt_lds_budget_kb * 1024u : kTopLdsBudget;
         const uint32_t room = budget > stack_bytes ? budget - stack_bytes : 0u;
-        lp.top_count = std::min<uint32_t>(S->top_avail, room / (uint32_t)sizeof(DNode));
+        lp.top_count = std::min<uint32_t>(T.top_avail, room / (uint32_t)sizeof(DNode));
         lp.nodes_off = 0;
         off = lp.top_count * (uint32_t)sizeof(DNode);
     } else if (res != 0) {
         lp.nodes_off = off;
-        off = align16(off + (res == 2 ? 8u * oct_table_pitch((uint32_t)S->dev.num_nodes, kLdsNodeStride)
-                                      : (uint32_t)S->dev.num_nodes * kLdsNodeStride));
+        off = align16(off + (res == 2 ? 8u * oct_table_pitch((uint32_t)T.num_nodes, kLdsNodeStride)
+                                      : (uint32_t)T.num_nodes * kLdsNodeStride));
         lp.prims_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DPrim));
         lp.normals_off = off; off = align16(off + (uint32_t)S->dev.num_prims * sizeof(DNormals));
         lp.mats_off = off; off = align16(off + (uint32_t)S->dev.num_materials * sizeof(DMaterial));
         lp.emis_off = off; off = align16(off + (uint32_t)std::max(S->dev.num_emission, 1) * sizeof(DEmission));
     }
     lp.stack_off = off;
-    off += (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * (stack16 ? 2u : 4u);
+    off += (uint32_t)(kBlock / 64) * (uint32_t)T.stack_cap * 64u * (stack16 ? 2u : 4u);
     lp.total = align16(off);
     return lp;
 }
@@ -459,10 +569,20 @@ TraceFn pick_kernel_nee(int res, bool stats, int spec) {
 }
 
 // Residency the next launch will use (see make_plan).
-int scene_residency(const pt_scene* S) {
+// The tree an exact / pruned render traverses: the internal surface-area-cost tree for exact traversal on the default kernel
+// (with reference-order reruns, see launch_render), the caller's tree otherwise.
+// Scenes that are staged whole in LDS stay on the caller's tree: there the reference's tree is as good as any (cbox: 14.76
+// inner visits per segment against 15.1 on a surface-area tree of the same depth; a deeper one costs a resident block).
+int which_tree(const pt_scene* S, int traversal) {
+    const bool global_scene = S->opt_force_global || S->scene_bytes > kLdsSceneLimit;
+    return (S->have_fast && S->opt_fast_tree && S->opt_kernel == 2 && traversal == PT_TRAVERSAL_EXACT && global_scene) ? 1 : 0;
+}
+
+int scene_residency(const pt_scene* S, int which = 0) {
+    const pt_scene::Tree& T = S->tree[which];
     if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit)
-        return (S->top_avail > 0 && S->opt_top_cache && S->opt_kernel == 2 && !S->opt_force_global) ? 3 : 0;
-    if (S->opt_kernel == 2 && S->opt_octants && S->dev.nodes_oct) return 2;
+        return (T.top_avail > 0 && S->opt_top_cache && S->opt_kernel == 2 && !S->opt_force_global) ? 3 : 0;
+    if (S->opt_kernel == 2 && S->opt_octants && T.have_oct) return 2;
     return 1;
 }
 
@@ -560,9 +680,13 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
 
     const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
-    const int res = scene_residency(S);
+    // Exact traversal runs on the internal tree and reruns, in reference order on the caller's tree, the rays whose closest
+    // hit depends on the visit order: two valid hits with equal t (the first one VISITED wins, scene.h:270) and rays with a
+    // zero direction component (1/d infinite: the monotonicity argument of validate_and_build does not cover 0 * inf).
+    const int which = which_tree(S, traversal);
+    const int res = scene_residency(S, which);
     const bool lds_scene = res == 1 || res == 2;
-    const LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel == 2);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
+    const LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel == 2, which);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
     if (p->flags & ~PT_RENDER_NEE) return fail(PT_ERR_INVALID_ARG, "unknown bits in pt_render_params.flags");
     const bool nee = (p->flags & PT_RENDER_NEE) != 0;
@@ -587,6 +711,12 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     S->info_lds_bytes = lp.total;
     S->info_lds_scene = lds_scene;
 
+    if (which == 1) {
+        // one global-memory stack column per lane of the grid for the reruns (rare: latency does not matter)
+        const size_t lanes = (size_t)S->num_cus * 8 * kBlock;
+        if ((rc = S->redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
+    }
+    select_tree(S, which, which == 1);
     float* accum = mode == 2 ? out_dev : S->accum.p;
     for (int pass = 0; pass < n_pass; pass++) {
         const int s0 = pass * (int)spp_pass;
@@ -705,7 +835,7 @@ int pt_scene_destroy(pt_scene* S) {
     DeviceGuard guard;
     (void)guard.enter(S->device);
     if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
-    S->nodes.release(); S->nodes_oct.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
+    for (auto& T : S->tree) { T.nodes.release(); T.nodes_oct.release(); } S->redo_stack.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
     S->lights.release(); S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->ctl.release();
     S->drop_events();
     delete S;
@@ -779,6 +909,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "xcd_regions") S->opt_xcd_regions = value;
     else if (k == "octants") S->opt_octants = value;
     else if (k == "top_cache") S->opt_top_cache = value;
+    else if (k == "fast_tree") S->opt_fast_tree = value;
     else if (k == "lds_budget_kb") S->opt_lds_budget_kb = value;
     else if (k == "chunk") S->opt_chunk = value;
     else if (k == "item_order") S->opt_item_order = value;
@@ -797,15 +928,27 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     if (k == "grid") *value = S->info_grid;
     else if (k == "lds_bytes") *value = S->info_lds_bytes;
     else if (k == "lds_scene") *value = S->info_lds_scene;
-    else if (k == "residency") *value = scene_residency(S);
+    else if (k == "residency") *value = scene_residency(S, which_tree(S, PT_TRAVERSAL_EXACT));
     else if (k == "passes") *value = S->info_passes;
     else if (k == "occupancy") *value = S->info_occupancy;                // what the occupancy query allows
     else if (k == "blocks_per_cu") *value = S->info_blocks_per_cu;        // what the last launch used
+    else if (k == "redo_segments") {                                     // STATS: segments rerun in reference order by the last render
+        DeviceGuard guard;
+        { int grc = guard.enter(S->device); if (grc) return grc; }
+        HIP_TRY(hipStreamSynchronize(S->last_stream));
+        unsigned long long c[kSlotStride] = {0};
+        if (S->ctl.p) { int rc = read_slot_sums(S, c); if (rc) return rc; }
+        *value = (int64_t)c[12];
+    }
     else if (k == "num_cus") *value = S->num_cus;
-    else if (k == "bvh_depth") *value = S->bvh_depth;
+    else if (k == "bvh_depth") *value = S->tree[0].depth;
+    else if (k == "fast_tree") *value = S->have_fast ? 1 : 0;             // an internal tree exists (the caller's tree is nested)
+    else if (k == "debug_reruns") *value = S->info_debug_reruns;          // rays the last pt_debug_intersect reran in reference order
+    else if (k == "fast_tree_cost_permille") *value = S->fast_cost_permille;   // summed inner-box area, internal tree / caller's tree x 1000 (0: none built)
+    else if (k == "fast_tree_depth") *value = S->have_fast ? S->tree[1].depth : 0;
     else if (k == "scene_bytes") *value = S->scene_bytes;
-    else if (k == "num_inner_nodes") *value = S->dev.num_nodes;
-    else if (k == "top_nodes") *value = make_plan(S, scene_residency(S), false).top_count;
+    else if (k == "num_inner_nodes") *value = S->tree[0].num_nodes;
+    else if (k == "top_nodes") { const int w = which_tree(S, PT_TRAVERSAL_EXACT); *value = make_plan(S, scene_residency(S, w), false, w).top_count; }
     else if (k == "device") *value = S->device;
     else if (k.rfind("diag", 0) == 0 && k.size() >= 5 && k.size() <= 7 && k.find_first_not_of("0123456789", 4) == std::string::npos &&
              std::stoi(k.substr(4)) < 8 + kNumCounters - kTimelineBase) {
@@ -827,7 +970,8 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     }
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
-        TraceFn fn = pick_kernel(S, scene_residency(S), k == "vgprs_pruned", S->opt_stats != 0);
+        const int w = which_tree(S, k == "vgprs_pruned" ? PT_TRAVERSAL_PRUNED : PT_TRAVERSAL_EXACT);
+        TraceFn fn = pick_kernel(S, scene_residency(S, w), k == "vgprs_pruned", S->opt_stats != 0);
         if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
         *value = fa.numRegs;
@@ -879,18 +1023,27 @@ int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, flo
     DeviceGuard guard;
     { int grc = guard.enter(S->device); if (grc) return grc; }
     DevBuf<float> dr, dt;
-    DevBuf<int32_t> dp;
+    DevBuf<int32_t> dp, dn;
     int rc;
-    if ((rc = dr.ensure((size_t)n * 8)) || (rc = dt.ensure((size_t)n * 3)) || (rc = dp.ensure(n))) return rc;
-    const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
+    if ((rc = dr.ensure((size_t)n * 8)) || (rc = dt.ensure((size_t)n * 3)) || (rc = dp.ensure(n)) || (rc = dn.ensure(1))) return rc;
+    // exact traversal: the internal tree with reference-order reruns when there is one (whatever the scene's size: this kernel
+    // reads nodes from global memory), so that the closest hits — ties included — can be checked ray by ray; else the caller's
+    const bool fast = S->have_fast && S->opt_fast_tree && traversal == PT_TRAVERSAL_EXACT;
+    select_tree(S, fast ? 1 : 0, fast);
+    const int cap = fast && S->dev.redo_cap > S->dev.stack_cap ? S->dev.redo_cap : S->dev.stack_cap;
+    const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)cap * 64u * 4u;
     hipError_t e = hipMemcpy(dr.p, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dn.p, 0, sizeof(int32_t));
     if (e == hipSuccess) {
         if (traversal == PT_TRAVERSAL_PRUNED)
-            hipLaunchKernelGGL(intersect_kernel<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, nullptr, S->dev, dr.p, n, dt.p, dp.p);
+            hipLaunchKernelGGL(intersect_kernel<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, nullptr, S->dev, dr.p, n, dt.p, dp.p, dn.p);
         else
-            hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, nullptr, S->dev, dr.p, n, dt.p, dp.p);
+            hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, nullptr, S->dev, dr.p, n, dt.p, dp.p, dn.p);
         e = hipGetLastError();
     }
+    int32_t reruns = 0;
+    if (e == hipSuccess) e = hipMemcpy(&reruns, dn.p, sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) S->info_debug_reruns = reruns;
     if (e == hipSuccess) e = hipMemcpy(out_tuv, dt.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_prim, dp.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("pt_debug_intersect: ") + hipGetErrorString(e));

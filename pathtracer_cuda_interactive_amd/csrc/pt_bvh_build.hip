@@ -5,7 +5,7 @@
 // README's machines (README.md:123,132), and a poor tree: it cuts through the middle of the object list wherever that
 // falls in space, and exact traversal (scene.h:258-297 never prunes) pays for every box a ray touches.
 //
-// Here the primitives are put in Morton order once (30-bit codes of the AABB centroids, ties by primitive id; rocPRIM
+// Here the primitives are put in Morton order once (63-bit codes of the AABB centroids, ties by primitive id; rocPRIM
 // radix sort) and stay there; every subtree is a contiguous range of that order, so the box of ANY candidate subtree is
 // a range query on a static array — answered by a bottom-up range tree over the sorted leaf boxes (min/max are exact
 // and associative: a query returns the same bits as a sequential merge).  Two builders on top of that:
@@ -104,37 +104,43 @@ __global__ __launch_bounds__(256) void centroid_bounds_kernel(const Box* __restr
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {      // 10 bits -> every third bit
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
+__device__ __forceinline__ uint64_t expand_bits21(uint64_t v) {      // 21 bits -> every third bit
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
-// key = morton30(centroid) << 32 | primitive id: a total order (ties by id), unique keys
-__global__ void morton_kernel(const Box* __restrict__ boxes, const Box* __restrict__ cbounds, int n, uint64_t* __restrict__ keys) {
+// 63-bit Morton code of the centroid (21 bits per axis: one far-away primitive — a ground sphere of radius 100 under a
+// unit-sized scene — stretches the centroid bounds by two orders of magnitude, and a 10-bit grid would then see the whole
+// rest of the scene in a handful of cells), with the primitive id as the sorted value; the sort is stable, so equal codes
+// stay in id order: a total, deterministic order.
+__global__ void morton_kernel(const Box* __restrict__ boxes, const Box* __restrict__ cbounds, int n, uint64_t* __restrict__ codes,
+                              uint32_t* __restrict__ ids) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Box b = boxes[i];
     const Box cb = cbounds[0];
-    uint32_t q[3];
+    uint64_t q[3];
     for (int k = 0; k < 3; k++) {
         const float c = (b.hi[k] + b.lo[k]) * 0.5f;
         const float ext = cb.hi[k] - cb.lo[k];
         float t = ext > 0.0f ? (c - cb.lo[k]) / ext : 0.0f;
-        t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
-        q[k] = (uint32_t)t;
+        t = fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f);
+        q[k] = (uint64_t)t;
     }
-    const uint32_t code = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
-    keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+    codes[i] = (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2]);
+    ids[i] = (uint32_t)i;
 }
 
 // ---- range tree over the sorted leaf boxes: tree[P + i] = box of sorted leaf i (empty beyond n), tree[k] = tree[2k] U tree[2k+1]
-__global__ void rangetree_leaves_kernel(const Box* __restrict__ boxes, const uint64_t* __restrict__ keys, int n, int P, Box* __restrict__ tree) {
+__global__ void rangetree_leaves_kernel(const Box* __restrict__ boxes, const uint32_t* __restrict__ ids, int n, int P, Box* __restrict__ tree) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    tree[P + i] = i < n ? boxes[(uint32_t)keys[i]] : box_empty();
+    tree[P + i] = i < n ? boxes[ids[i]] : box_empty();
 }
 __global__ void rangetree_level_kernel(Box* __restrict__ tree, int first, int count) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,18 +171,17 @@ __device__ __forceinline__ void write_node(pt_bvh_node* out, int slot, const Box
 // ---- LBVH (Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012) ----------
 // Virtual key of sorted position i: {morton code, i} — positions of equal codes are consecutive integers, so a run of
 // duplicates becomes a balanced subtree.  delta = length of the common prefix of two virtual keys (-1 outside [0,n)).
-__device__ __forceinline__ int lbvh_delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+__device__ __forceinline__ int lbvh_delta(const uint64_t* __restrict__ codes, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const uint64_t a = (keys[i] & 0xffffffff00000000ull) | (uint32_t)i;
-    const uint64_t b = (keys[j] & 0xffffffff00000000ull) | (uint32_t)j;
-    return __builtin_clzll(a ^ b);
+    const uint64_t x = codes[i] ^ codes[j];
+    return x ? __builtin_clzll(x) : 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);     // (i != j here)
 }
 
 // Output layout: leaves at slots [0, n) in sorted order, inner node i at slot n + i, root = slot n (inner node 0).
-__global__ void lbvh_kernel(const uint64_t* __restrict__ keys, const Box* __restrict__ tree, int P, int n,
+__global__ void lbvh_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, const Box* __restrict__ tree, int P, int n,
                             pt_bvh_node* __restrict__ out, int* __restrict__ parent) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) write_node(out, i, tree[P + i], -1, -1, (int)(uint32_t)keys[i]);
+    if (i < n) write_node(out, i, tree[P + i], -1, -1, (int)ids[i]);
     if (i >= n - 1) return;
     const int d = lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
     const int dmin = lbvh_delta(keys, n, i, i - d);
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void sah_cost_kernel(const SahPos* __restrict_
 
 // apply the cuts: every position moves into its child; the first position of a node writes the node, of a new leaf the leaf
 __global__ __launch_bounds__(256) void sah_split_kernel(SahPos* __restrict__ pos, const Box* __restrict__ tree, int P, int n,
-                                                        const uint64_t* __restrict__ keys, unsigned long long* __restrict__ best,
+                                                        const uint32_t* __restrict__ ids, unsigned long long* __restrict__ best,
                                                         int depth, int max_depth, pt_bvh_node* __restrict__ out,
                                                         int* __restrict__ parent, int* __restrict__ n_active) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void sah_split_kernel(SahPos* __restrict__ pos
     if (i < m) c = SahPos{p.lo, m, lbase}; else c = SahPos{m, p.hi, rbase};
     pos[i] = c;
     if (c.hi - c.lo == 1) {
-        write_node(out, c.base, tree[P + i], -1, -1, (int)(uint32_t)keys[i]);       // a one-leaf subtree owns exactly slot `base`
+        write_node(out, c.base, tree[P + i], -1, -1, (int)ids[i]);       // a one-leaf subtree owns exactly slot `base`
     } else {
         if (i == c.lo) { best[c.base + 2 * (c.hi - c.lo) - 2] = kNoCut; atomicAdd(n_active, 1); }
     }
@@ -304,7 +309,104 @@ struct Dev {
     }
 };
 
+// Everything after the primitive boxes: Morton order, range tree, hierarchy, depth, copy back.  d_boxes: n boxes on the device.
+int bvh_build_core(const Box* d_boxes, int n, int method, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
+                   hipEvent_t e0, hipEvent_t e1, double* out_build_ms, int depth_cap = 0) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    const int n_nodes = 2 * n - 1;
+    Dev<Box> d_part, d_tree;
+    Dev<uint64_t> d_keys, d_keys2; Dev<uint32_t> d_ids, d_ids2; Dev<pt_bvh_node> d_out; Dev<int> d_parent, d_misc; Dev<SahPos> d_sp;
+    Dev<unsigned long long> d_best; Dev<unsigned char> d_tmp;
+    int rc;
+    if ((rc = d_part.alloc(1024 + 1)) || (rc = d_tree.alloc(2 * (size_t)P)) || (rc = d_keys.alloc(n)) ||
+        (rc = d_keys2.alloc(n)) || (rc = d_ids.alloc(n)) || (rc = d_ids2.alloc(n)) || (rc = d_out.alloc(n_nodes)) || (rc = d_parent.alloc(n_nodes)) || (rc = d_misc.alloc(4)))
+        return rc;
+    size_t tmp_bytes = 0;
+    HIPB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_ids.p, d_ids2.p, (size_t)n, 0, 63, nullptr));
+    if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
+    if (method == PT_BVH_DEVICE_SAH && ((rc = d_sp.alloc(n)) || (rc = d_best.alloc(n_nodes)))) return rc;
+
+    const int B = 256;
+    const auto G = [&](int count) { return dim3((unsigned)((count + B - 1) / B)); };
+    const int parts = std::min(1024, (n + B - 1) / B);
+    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(parts), dim3(B), 0, nullptr, d_boxes, n, 0, d_part.p + 1);
+    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(1), dim3(B), 0, nullptr, d_part.p + 1, parts, 1, d_part.p);
+    hipLaunchKernelGGL(morton_kernel, G(n), dim3(B), 0, nullptr, d_boxes, d_part.p, n, d_keys.p, d_ids.p);
+    HIPB(hipGetLastError());
+    HIPB(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_ids.p, d_ids2.p, (size_t)n, 0, 63, nullptr));
+    const uint64_t* keys = d_keys2.p;
+    const uint32_t* ids = d_ids2.p;
+    hipLaunchKernelGGL(rangetree_leaves_kernel, G(P), dim3(B), 0, nullptr, d_boxes, ids, n, P, d_tree.p);
+    for (int first = P / 2; first >= 1; first /= 2)
+        hipLaunchKernelGGL(rangetree_level_kernel, G(first), dim3(B), 0, nullptr, d_tree.p, first, first);
+    HIPB(hipGetLastError());
+    HIPB(hipMemsetAsync(d_misc.p, 0, 4 * sizeof(int), nullptr));
+
+    int root = 0;
+    if (method == PT_BVH_DEVICE_LBVH) {
+        hipLaunchKernelGGL(lbvh_kernel, G(n), dim3(B), 0, nullptr, keys, ids, d_tree.p, P, n, d_out.p, d_parent.p);
+        HIPB(hipGetLastError());
+        root = n;
+    } else {
+        hipLaunchKernelGGL(sah_init_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, n, d_best.p);
+        // Depth cap (leaves count 1): ceil(log2 n) + 5.  The kernel keeps one LDS stack entry per level and lane, so a
+        // deep tree takes LDS from the top-of-tree cache and, beyond ~30 levels, a resident block per CU; the cap costs
+        // little (bunny: 22.6 inner visits per segment uncapped at depth 28, 23.3 capped at 24, 32.1 at 22)
+        int lg = 0;
+        while ((1 << lg) < n) lg++;
+        const int max_depth = depth_cap > 0 ? std::min(48, std::max(lg + 1, depth_cap)) : std::min(48, std::max(8, lg + 5));
+        for (int depth = 1; depth < max_depth; depth++) {
+            hipLaunchKernelGGL(sah_cost_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, d_tree.p, P, n, d_best.p);
+            HIPB(hipMemsetAsync(d_misc.p + 1, 0, sizeof(int), nullptr));
+            hipLaunchKernelGGL(sah_split_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, d_tree.p, P, n, ids, d_best.p, depth, max_depth,
+                               d_out.p, d_parent.p, d_misc.p + 1);
+            HIPB(hipGetLastError());
+            if (depth % 4 == 0) {           // nodes still to be cut after this level?
+                int active = 0;
+                HIPB(hipMemcpy(&active, d_misc.p + 1, sizeof(int), hipMemcpyDeviceToHost));
+                if (active == 0) break;
+            }
+        }
+        root = n_nodes - 1;
+    }
+    hipLaunchKernelGGL(depth_kernel, G(n_nodes), dim3(B), 0, nullptr, d_parent.p, n_nodes, d_misc.p);
+    HIPB(hipGetLastError());
+    HIPB(hipEventRecord(e1, nullptr));
+    HIPB(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPB(hipEventElapsedTime(&ms, e0, e1));
+    int depth = 0;
+    HIPB(hipMemcpy(&depth, d_misc.p, sizeof(int), hipMemcpyDeviceToHost));
+    HIPB(hipMemcpy(out_nodes, d_out.p, (size_t)n_nodes * sizeof(pt_bvh_node), hipMemcpyDeviceToHost));
+    *out_root = root;
+    if (out_depth) *out_depth = depth;
+    if (out_build_ms) *out_build_ms = ms;
+    return PT_OK;
+}
+
+struct EvGuard {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
 }  // namespace
+
+// Internal entry for pt_scene_create: the hierarchy over GIVEN primitive boxes (n x {min xyz, max xyz}, host memory) — the
+// leaf boxes of the caller's own tree, so that both trees test the very same boxes before a primitive.
+int pt_bvh_build_from_boxes(const float* boxes, int n, int method, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
+                            int depth_cap) {
+    if (n < 2) return pt_fail(PT_ERR_INVALID_ARG, "needs at least two primitives");
+    Dev<Box> d_boxes;
+    int rc;
+    if ((rc = d_boxes.alloc(n))) return rc;
+    HIPB(hipMemcpy(d_boxes.p, boxes, (size_t)n * sizeof(Box), hipMemcpyHostToDevice));
+    EvGuard evg;
+    HIPB(hipEventCreate(&evg.a));
+    HIPB(hipEventCreate(&evg.b));
+    HIPB(hipEventRecord(evg.a, nullptr));
+    return bvh_build_core(d_boxes.p, n, method, out_nodes, out_root, out_depth, evg.a, evg.b, nullptr, depth_cap);
+}
 
 extern "C" int pt_bvh_build_device(const pt_scene_desc* d, int method, pt_bvh_node* out_nodes, int32_t* out_root,
                                    int32_t* out_depth, double* out_build_ms) {
@@ -376,87 +478,18 @@ extern "C" int pt_bvh_build_device(const pt_scene_desc* d, int method, pt_bvh_no
         return PT_OK;
     }
 
-    int P = 1;
-    while (P < n) P <<= 1;
-    const int n_nodes = 2 * n - 1;
-    Dev<DevShape> d_shapes; Dev<float> d_pos; Dev<int32_t> d_idx; Dev<Box> d_boxes, d_part, d_tree;
-    Dev<uint64_t> d_keys, d_keys2; Dev<pt_bvh_node> d_out; Dev<int> d_parent, d_misc; Dev<SahPos> d_sp;
-    Dev<unsigned long long> d_best; Dev<unsigned char> d_tmp;
+    Dev<DevShape> d_shapes; Dev<float> d_pos; Dev<int32_t> d_idx; Dev<Box> d_boxes;
     int rc;
-    if ((rc = d_shapes.alloc(n)) || (rc = d_pos.alloc(positions.size())) || (rc = d_idx.alloc(indices.size())) ||
-        (rc = d_boxes.alloc(n)) || (rc = d_part.alloc(1024 + 1)) || (rc = d_tree.alloc(2 * (size_t)P)) || (rc = d_keys.alloc(n)) ||
-        (rc = d_keys2.alloc(n)) || (rc = d_out.alloc(n_nodes)) || (rc = d_parent.alloc(n_nodes)) || (rc = d_misc.alloc(4)))
+    if ((rc = d_shapes.alloc(n)) || (rc = d_pos.alloc(positions.size())) || (rc = d_idx.alloc(indices.size())) || (rc = d_boxes.alloc(n)))
         return rc;
     HIPB(hipMemcpy(d_shapes.p, shapes.data(), shapes.size() * sizeof(DevShape), hipMemcpyHostToDevice));
     if (!positions.empty()) HIPB(hipMemcpy(d_pos.p, positions.data(), positions.size() * 4, hipMemcpyHostToDevice));
     if (!indices.empty()) HIPB(hipMemcpy(d_idx.p, indices.data(), indices.size() * 4, hipMemcpyHostToDevice));
-    size_t tmp_bytes = 0;
-    HIPB(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.p, d_keys2.p, (size_t)n, 0, 64, nullptr));
-    if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
-    if (method == PT_BVH_DEVICE_SAH && ((rc = d_sp.alloc(n)) || (rc = d_best.alloc(n_nodes)))) return rc;
-
-    struct EvGuard {
-        hipEvent_t a = nullptr, b = nullptr;
-        ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    } evg;
+    EvGuard evg;
     HIPB(hipEventCreate(&evg.a));
     HIPB(hipEventCreate(&evg.b));
-    const hipEvent_t e0 = evg.a, e1 = evg.b;
-    const int B = 256;
-    const auto G = [&](int count) { return dim3((unsigned)((count + B - 1) / B)); };
-    HIPB(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(prim_bounds_kernel, G(n), dim3(B), 0, nullptr, d_shapes.p, d_pos.p, d_idx.p, n, d_boxes.p);
-    const int parts = std::min(1024, (n + B - 1) / B);
-    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(parts), dim3(B), 0, nullptr, d_boxes.p, n, 0, d_part.p + 1);
-    hipLaunchKernelGGL(centroid_bounds_kernel, dim3(1), dim3(B), 0, nullptr, d_part.p + 1, parts, 1, d_part.p);
-    hipLaunchKernelGGL(morton_kernel, G(n), dim3(B), 0, nullptr, d_boxes.p, d_part.p, n, d_keys.p);
+    HIPB(hipEventRecord(evg.a, nullptr));
+    hipLaunchKernelGGL(prim_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_shapes.p, d_pos.p, d_idx.p, n, d_boxes.p);
     HIPB(hipGetLastError());
-    HIPB(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, (size_t)n, 0, 64, nullptr));
-    const uint64_t* keys = d_keys2.p;
-    hipLaunchKernelGGL(rangetree_leaves_kernel, G(P), dim3(B), 0, nullptr, d_boxes.p, keys, n, P, d_tree.p);
-    for (int first = P / 2; first >= 1; first /= 2)
-        hipLaunchKernelGGL(rangetree_level_kernel, G(first), dim3(B), 0, nullptr, d_tree.p, first, first);
-    HIPB(hipGetLastError());
-    HIPB(hipMemsetAsync(d_misc.p, 0, 4 * sizeof(int), nullptr));
-
-    int root = 0;
-    if (method == PT_BVH_DEVICE_LBVH) {
-        hipLaunchKernelGGL(lbvh_kernel, G(n), dim3(B), 0, nullptr, keys, d_tree.p, P, n, d_out.p, d_parent.p);
-        HIPB(hipGetLastError());
-        root = n;
-    } else {
-        hipLaunchKernelGGL(sah_init_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, n, d_best.p);
-        // Depth cap (leaves count 1): ceil(log2 n) + 5.  The kernel keeps one LDS stack entry per level and lane, so a
-        // deep tree takes LDS from the top-of-tree cache and, beyond ~30 levels, a resident block per CU; the cap costs
-        // little (bunny: 22.6 inner visits per segment uncapped at depth 28, 23.3 capped at 24, 32.1 at 22)
-        int lg = 0;
-        while ((1 << lg) < n) lg++;
-        const int max_depth = std::min(48, std::max(8, lg + 5));
-        for (int depth = 1; depth < max_depth; depth++) {
-            hipLaunchKernelGGL(sah_cost_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, d_tree.p, P, n, d_best.p);
-            HIPB(hipMemsetAsync(d_misc.p + 1, 0, sizeof(int), nullptr));
-            hipLaunchKernelGGL(sah_split_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, d_tree.p, P, n, keys, d_best.p, depth, max_depth,
-                               d_out.p, d_parent.p, d_misc.p + 1);
-            HIPB(hipGetLastError());
-            if (depth % 4 == 0) {           // nodes still to be cut after this level?
-                int active = 0;
-                HIPB(hipMemcpy(&active, d_misc.p + 1, sizeof(int), hipMemcpyDeviceToHost));
-                if (active == 0) break;
-            }
-        }
-        root = n_nodes - 1;
-    }
-    hipLaunchKernelGGL(depth_kernel, G(n_nodes), dim3(B), 0, nullptr, d_parent.p, n_nodes, d_misc.p);
-    HIPB(hipGetLastError());
-    HIPB(hipEventRecord(e1, nullptr));
-    HIPB(hipEventSynchronize(e1));
-    float ms = 0;
-    HIPB(hipEventElapsedTime(&ms, e0, e1));
-    int depth = 0;
-    HIPB(hipMemcpy(&depth, d_misc.p, sizeof(int), hipMemcpyDeviceToHost));
-    HIPB(hipMemcpy(out_nodes, d_out.p, (size_t)n_nodes * sizeof(pt_bvh_node), hipMemcpyDeviceToHost));
-    *out_root = root;
-    if (out_depth) *out_depth = depth;
-    if (out_build_ms) *out_build_ms = ms;
-    return PT_OK;
+    return bvh_build_core(d_boxes.p, n, method, out_nodes, out_root, out_depth, evg.a, evg.b, out_build_ms);
 }

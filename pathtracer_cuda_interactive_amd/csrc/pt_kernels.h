@@ -192,7 +192,8 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
 // pt_counters: per-wave sums, one atomic per wave and counter.  Same-address atomics serialise in L2 (~5 ns each:
 // 12 k of them at the end of a 6144-wave launch were ~60 us of every frame), so the sums are spread over kCounterSlots
 // slots of one 128-B line each, picked by workgroup id; the host adds the slots up (pt_get_counters).
-// Slot layout (uint64): [0] paths [1] segments [2] node visits [3] leaf tests [4..11] schedule diagnostics.
+// Slot layout (uint64): [0] paths [1] segments [2] node visits [3] leaf tests [4..11] schedule diagnostics
+// [12] segments rerun in reference order (exact traversal on the internal tree).
 // After the slots: launch timeline [kTimelineBase + 0..7] and two 128-bin histograms (STATS builds only).
 constexpr int kCounterSlots = 64;
 constexpr int kSlotStride = 16;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
     ptd::Trav tv;
     tv.inv = ptm::mk(1, 1, 1);
     tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
-    tv.cur = DONE; tv.sp = 1; tv.node_off = 0;
+    tv.cur = DONE; tv.sp = 1; tv.node_off = 0; tv.redo = false;
     ptd::stack_init(stk);
     ptm::V3 L = ptm::mk(0, 0, 0), T = ptm::mk(1, 1, 1);
     ptm::Pcg rng;
@@ -343,6 +344,14 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
     uint32_t n_paths = 0, n_segs = 0;
     ptd::TravStats st;
     st.nodes = 0; st.leaves = 0;
+    // exact traversal on the internal tree (scn.fallback): reruns in reference order use the caller's tree and a
+    // global-memory stack column of their own (the LDS columns belong to the lanes that are still traversing)
+    const bool fbk = scn.fallback != 0;                       // wave-uniform
+    ptd::SceneView sv_ref = sv;
+    sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref; sv_ref.node_stride = sizeof(DNode);
+    sv_ref.oct_stride = 0; sv_ref.top_nodes = nullptr; sv_ref.top_count = 0;
+    int32_t* redo_stk = scn.redo_stack + ((size_t)(blockIdx.x * (kBlock / 64) + wave) * (size_t)scn.redo_cap) * 64 + lane;
+    uint32_t n_redo = 0;
     // next-event estimation: the lane is tracing the shadow ray of its light sample; what it resumes with afterwards
     ptd::NeeState nee;
     nee.count_emission = true; nee.want_shadow = false;
@@ -372,6 +381,14 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
             if (n_pend == 0) break;          // every lane idle, no live path, no work left
             if (STATS) { dg_sched++; dg_sched_lanes += (unsigned)n_pend; }
             // (1) finish the segments whose traversal completed (radiance.cuh:26-75)
+            if (fbk && idle && alive && tv.redo) {
+                // the closest hit of this ray depends on the visit order: trace it again the reference's way, to completion
+                ptd::TravStats st_redo;
+                st_redo.nodes = 0; st_redo.leaves = 0;
+                tv.best = ptd::intersect<false, false>(sv_ref, ray, redo_stk, st_redo);
+                tv.redo = false;
+                if (STATS) n_redo++;
+            }
             if (idle && alive) {
                 bool cont = false;
                 if (NEE && in_shadow) {
@@ -428,6 +445,12 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
             if (idle && alive) {
                 ptd::trav_begin(sv, ray, tv);
                 if (!(NEE && in_shadow)) n_segs++;          // "segments" = intersect() calls; shadow rays are not counted
+                // 1/d infinite on an axis: 0 * inf in the slab test is outside the argument that lets another tree stand in
+                // for the caller's (pt_api.hip: validate_and_build) -> straight to the reference-order rerun
+                if (fbk && !(__builtin_isfinite(tv.inv.x) && __builtin_isfinite(tv.inv.y) && __builtin_isfinite(tv.inv.z))) {
+                    tv.redo = true;
+                    tv.cur = DONE;
+                }
             }
         }
         // ---- traversal burst
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
                     }
                 } else if (at_leaf) {
                     if (STATS) st.leaves++;
-                    ptd::leaf_step<STK, TRI_ONLY, NEE>(sv, ray, tv, stk, NEE && in_shadow);
+                    ptd::leaf_step<STK, TRI_ONLY, NEE>(sv, ray, tv, stk, NEE && in_shadow, fbk);
                 }
             }
         } else {
@@ -480,19 +503,21 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
                     }
                     if (tv.cur < 0 && tv.cur != DONE) {
                         if (STATS) st.leaves++;
-                        ptd::leaf_step<STK, TRI_ONLY, NEE>(sv, ray, tv, stk, NEE && in_shadow);
+                        ptd::leaf_step<STK, TRI_ONLY, NEE>(sv, ray, tv, stk, NEE && in_shadow, fbk);
                     }
                 }
             }
         }
     }
     flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
+    const unsigned long long redo_sum = STATS ? wave_sum(n_redo) : 0ull;
     if (STATS && lane == 0) {
         const unsigned long long tl_exit = wall_clock64();
         unsigned long long* slot = counter_slot(counters);
         atomicAdd(&slot[4], dg_iter); atomicAdd(&slot[5], dg_sched); atomicAdd(&slot[6], dg_sched_lanes);
         atomicAdd(&slot[7], dg_in); atomicAdd(&slot[8], dg_in_lanes); atomicAdd(&slot[9], dg_lf);
         atomicAdd(&slot[10], dg_lf_lanes); atomicAdd(&slot[11], dg_wait);
+        atomicAdd(&slot[12], redo_sum);
         // timeline, in 10-ns ticks: [0] ~(earliest entry)  [1] latest staged  [2] ~(earliest dry)  [3] latest dry
         // [4] latest exit  [5] sum over waves of (exit - dry)  [6] sum of (dry - staged)  [7] waves
         unsigned long long* tl = counters + kTimelineBase;
@@ -535,7 +560,47 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
 
 template <bool PRUNE>
 __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const float* __restrict__ rays, int n,
-                                                           float* __restrict__ out_tuv, int32_t* __restrict__ out_prim) {
+                                                           float* __restrict__ out_tuv, int32_t* __restrict__ out_prim,
+                                                           int32_t* __restrict__ reruns) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ptd::SceneView sv;
+    sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
+    sv.materials = scn.materials; sv.emission = scn.emission; sv.lights = scn.lights;
+    sv.top_nodes = nullptr; sv.top_count = 0;
+    sv.node_stride = sizeof(DNode);
+    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
+    sv.bg = ptm::mk(0, 0, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cap = scn.fallback && scn.redo_cap > scn.stack_cap ? scn.redo_cap : scn.stack_cap;   // one column serves both trees
+    int32_t* stk = reinterpret_cast<int32_t*>(smem) + (size_t)wave * cap * 64 + lane;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    ptd::Ray r;
+    r.org = ptm::mk(rays[8 * k], rays[8 * k + 1], rays[8 * k + 2]);
+    r.dir = ptm::mk(rays[8 * k + 3], rays[8 * k + 4], rays[8 * k + 5]);
+    r.tnear = rays[8 * k + 6];
+    r.tfar = rays[8 * k + 7];
+    ptd::TravStats st;
+    ptd::Hit h;
+    if (!PRUNE && scn.fallback) {                         // internal tree, reference-order rerun where the order matters
+        ptd::SceneView sv_ref = sv;
+        sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref;
+        bool rerun;
+        h = ptd::intersect_any_tree(sv, sv_ref, r, stk, rerun);
+        if (rerun) atomicAdd(reruns, 1);
+    } else {
+        h = ptd::intersect<PRUNE, false>(sv, r, stk, st);
+    }
+    out_prim[k] = h.prim;
+    out_tuv[3 * k] = h.prim < 0 ? 0.0f : h.t;
+    out_tuv[3 * k + 1] = h.prim < 0 ? 0.0f : h.u;
+    out_tuv[3 * k + 2] = h.prim < 0 ? 0.0f : h.v;
+}
+
+// Inner-node visits of a fixed set of probe rays through the tree `scn` points at (pt_api.hip: validate_and_build chooses
+// between the caller's tree and the internal one by this count).  Ray k starts on primitive hash(k) mod N — its centroid,
+// or the point of a sphere facing the direction — and leaves into a uniform direction: the shape of a segment after a bounce.
+__global__ __launch_bounds__(kBlock) void probe_kernel(SceneDev scn, unsigned long long* __restrict__ visits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ptd::SceneView sv;
     sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
@@ -546,19 +611,28 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     sv.bg = ptm::mk(0, 0, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* stk = reinterpret_cast<int32_t*>(smem) + (size_t)wave * scn.stack_cap * 64 + lane;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    ptm::Pcg rng = ptm::pcg_init(k, 0x9e3779b9u);
+    const uint32_t prim = (uint32_t)(((unsigned long long)ptm::pcg_next(rng) * (unsigned long long)scn.num_prims) >> 32);
+    const float z = 1.0f - 2.0f * ptm::pcg_float(rng);
+    const float phi = 6.2831853f * ptm::pcg_float(rng);
+    const float rr = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
     ptd::Ray r;
-    r.org = ptm::mk(rays[8 * k], rays[8 * k + 1], rays[8 * k + 2]);
-    r.dir = ptm::mk(rays[8 * k + 3], rays[8 * k + 4], rays[8 * k + 5]);
-    r.tnear = rays[8 * k + 6];
-    r.tfar = rays[8 * k + 7];
+    r.dir = ptm::mk(rr * __builtin_cosf(phi), rr * __builtin_sinf(phi), z);
+    const DPrim* pr = scn.prims + prim;
+    const float4 a = ptd::ld4(pr, 0), b = ptd::ld4(pr, 1), c = ptd::ld4(pr, 2);
+    if (__builtin_bit_cast(int32_t, c.y) < 0) {          // sphere: center + radius * dir
+        r.org = ptm::mk(a.x + a.w * r.dir.x, a.y + a.w * r.dir.y, a.z + a.w * r.dir.z);
+    } else {
+        r.org = ptm::mk((a.x + a.w + b.z) * (1.0f / 3.0f), (a.y + b.x + b.w) * (1.0f / 3.0f), (a.z + b.y + c.x) * (1.0f / 3.0f));
+    }
+    r.tnear = 1e-4f;
+    r.tfar = FLT_MAX;
     ptd::TravStats st;
-    const ptd::Hit h = ptd::intersect<PRUNE, false>(sv, r, stk, st);
-    out_prim[k] = h.prim;
-    out_tuv[3 * k] = h.prim < 0 ? 0.0f : h.t;
-    out_tuv[3 * k + 1] = h.prim < 0 ? 0.0f : h.u;
-    out_tuv[3 * k + 2] = h.prim < 0 ? 0.0f : h.v;
+    st.nodes = 0; st.leaves = 0;
+    (void)ptd::intersect<false, true>(sv, r, stk, st);
+    const unsigned long long sum = wave_sum((unsigned long long)st.nodes);
+    if (lane == 0) atomicAdd(visits, sum);
 }
 
 __global__ void math_kernel(int op, const float* __restrict__ x, const float* __restrict__ y,

@@ -73,6 +73,12 @@ struct SceneDev {
     int32_t root_ref;
     int32_t stack_cap;              // entries per lane needed (= BVH depth)
     float bg[3];
+    // exact traversal on the internal tree: rays whose result depends on the visit order are rerun on the caller's tree
+    int32_t fallback;               // 1 = `nodes` is the internal tree; ties on t / infinite 1/d trigger a reference-order rerun
+    const DNode* ref_nodes;         // the caller's tree (plain layout, global memory)
+    int32_t ref_root_ref;
+    int32_t redo_cap;               // stack entries per lane of a rerun
+    int32_t* redo_stack;            // [waves of the grid][redo_cap][64]
 };
 
 // Division of a number below 2^30 by a launch constant: q = (n * mul) >> shift, exact for every n < 2^30

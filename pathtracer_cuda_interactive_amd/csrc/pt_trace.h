@@ -65,6 +65,8 @@ struct Trav {
     int32_t cur;       // node reference being visited; kDone = traversal finished
     int32_t sp;        // entries on this lane's LDS stack column
     uint32_t node_off; // byte offset of the node table this ray reads (octant copy), 0 when there is one table
+    bool redo;         // traversal of the internal tree: the closest hit depends on the visit order (two hits tied on t, or
+                       // 1/d infinite) — this ray is traced again on the caller's tree in the reference's order
 };
 
 // The traversal stack lives in LDS, one column per lane (entry k at stk[k*64]).  Its element type STK is int32_t, or
@@ -79,6 +81,7 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
     t.best.t = FLT_MAX; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = -1;
     t.cur = sv.root_ref;           // scene.h:256: the root is pushed without a box test
     t.sp = 1;                      // entry 0 is the kDone sentinel
+    t.redo = false;
     // octant = which of the swaps of bbox.cuh:40-55 apply to this ray (inv < 0 per axis)
     const uint32_t oct = (t.inv.x < 0.0f ? 1u : 0u) | (t.inv.y < 0.0f ? 2u : 0u) | (t.inv.z < 0.0f ? 4u : 0u);
     t.node_off = oct * sv.oct_stride;
@@ -184,7 +187,8 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
 // TRI_ONLY: the scene holds no sphere, the sphere branch is compiled out.
 // ANYHIT (kernels built with next-event estimation): a lane tracing a shadow ray (`shadow`) stops at the first hit.
 template <class STK, bool TRI_ONLY, bool ANYHIT = false>
-__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk, const bool shadow = false) {
+__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk, const bool shadow = false,
+                                          const bool ties = false) {
     const int32_t prim = ~t.cur;
     const DPrim* pr = sv.prims + prim;
     const float4 a = ld4(pr, 0);
@@ -206,8 +210,9 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             const V3 s2 = cross(s, e1);
             const float v = dot(ray.dir, s2) * inv_divisor;
             const float tt = dot(e2, s2) * inv_divisor;
-            if (tt > ray.tnear && tt < ray.tfar && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && tt < t.best.t) {
-                t.best.t = tt; t.best.u = u; t.best.v = v; t.best.prim = prim;
+            if (tt > ray.tnear && tt < ray.tfar && u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
+                if (ties && tt == t.best.t) t.redo = true;          // the reference keeps the first one VISITED: its order decides
+                if (tt < t.best.t) { t.best.t = tt; t.best.u = u; t.best.v = v; t.best.prim = prim; }
             }
         }
     } else {
@@ -236,8 +241,9 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
             float tt = t0;
             if (t1 >= ray.tnear && t1 < ray.tfar && tt < ray.tnear) tt = t1;
-            if (tt >= ray.tnear && tt < ray.tfar && tt < t.best.t) {
-                t.best.t = tt; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = prim;
+            if (tt >= ray.tnear && tt < ray.tfar) {
+                if (ties && tt == t.best.t) t.redo = true;
+                if (tt < t.best.t) { t.best.t = tt; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = prim; }
             }
         }
     }
@@ -264,6 +270,28 @@ __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, in
         }
     }
     return t.best;
+}
+
+// The same closest hit — ties and all — traversed on ANOTHER tree over the same leaf boxes (`sv`), with the caller's tree
+// (`sv_ref`) kept for the rays whose answer depends on the visit order: two candidates at equal t, or a direction with a
+// zero component (pt_api.hip: validate_and_build has the argument).  The trace kernel inlines the same three steps into its
+// scheduler; this run-to-completion form serves pt_debug_intersect.  `rerun` reports that the reference order was needed.
+__device__ __forceinline__ Hit intersect_any_tree(const SceneView& sv, const SceneView& sv_ref, const Ray& ray, int32_t* stk, bool& rerun) {
+    Trav t;
+    TravStats st;
+    st.nodes = 0; st.leaves = 0;
+    stack_init(stk);
+    trav_begin(sv, ray, t);
+    if (!(__builtin_isfinite(t.inv.x) && __builtin_isfinite(t.inv.y) && __builtin_isfinite(t.inv.z))) {
+        t.redo = true;
+        t.cur = kDone;
+    }
+    while (t.cur != kDone) {
+        while (t.cur >= 0) inner_step<false, false, int32_t>(sv, ray.org, t, stk);
+        if (t.cur != kDone) leaf_step<int32_t, false>(sv, ray, t, stk, false, true);
+    }
+    rerun = t.redo;
+    return t.redo ? intersect<false, false>(sv_ref, ray, stk, st) : t.best;
 }
 
 // Surface record of the closest hit (scene.h:186-217 / shape.cuh:168-180).

@@ -62,9 +62,12 @@ def test_device_built_tree_is_valid_and_renders_like_the_oracle_on_it(oracle, me
     ds = dev.DeviceScene(d2)
     try:
         ds.set_option("stats", 1)
+        ds.set_option("fast_tree", 0)             # traverse the tree that was handed in: its visit count is the oracle's
         img = ds.render(p)
         c = ds.counters()
         assert ds.info("bvh_depth") == depth
+        ds.set_option("fast_tree", 1)             # default: an internal tree over the same leaf boxes — the same image
+        assert (ds.render(p).view(np.uint32) == img.view(np.uint32)).all()
     finally:
         ds.close()
     assert_bit_equal(img, want, f"{name} {method}")

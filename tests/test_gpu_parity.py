@@ -89,9 +89,21 @@ def test_device_matches_live_oracle(oracle, dscenes, name, w, h, spp):
     ds.set_option("stats", 1)
     img = ds.render(p, traversal=PT_TRAVERSAL_EXACT)
     c = ds.counters()
-    ds.set_option("stats", 0)
     assert_bit_equal(img, want, name)
-    # work counters agree with the oracle's: same paths, same segments, same node visits / primitive tests
+    assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
+    if ds.info("fast_tree") and ds.info("residency") in (0, 3):
+        # Scenes in global memory are traversed on the internal surface-area tree: the SAME leaves are tested (a leaf is
+        # tested iff the ray hits its own box, whatever the tree above it), in fewer node visits; the few rays whose closest
+        # hit depends on the visit order are rerun in reference order, which the leaf counter sees as extra tests.
+        assert c.node_visits < cnt.inner_pops
+        assert 0 <= c.leaf_tests - (cnt.leaf_tri + cnt.leaf_sphere) <= 64 * (1 + ds.info("redo_segments"))
+        ds.set_option("fast_tree", 0)
+        img = ds.render(p, traversal=PT_TRAVERSAL_EXACT)
+        c = ds.counters()
+        ds.set_option("fast_tree", 1)
+        assert_bit_equal(img, want, name + " on the caller's tree")
+    ds.set_option("stats", 0)
+    # on the caller's tree the work counters agree with the oracle's: same node visits, same primitive tests
     assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
     assert c.node_visits == cnt.inner_pops and c.leaf_tests == cnt.leaf_tri + cnt.leaf_sphere
     # pruned traversal is NOT guaranteed bit-exact (a triangle's t can round below its box's entry distance: DESIGN.md §6):
@@ -148,6 +160,11 @@ def test_top_of_tree_cache_does_not_change_the_image(oracle, dscenes, name):
     p = hs.render_params(64, 48, 5, seed=8)
     want, cnt = oracle.render(d, p)
     assert ds.info("residency") == 3 and ds.info("top_nodes") > 0
+    assert_bit_equal(ds.render(p), want, name + " internal tree, top of it in LDS")       # the default path
+    ds.set_option("top_cache", 0)
+    assert_bit_equal(ds.render(p), want, name + " internal tree, all nodes from global memory")
+    ds.set_option("top_cache", 1)
+    ds.set_option("fast_tree", 0)                 # the caller's tree: the work counters must equal the oracle's
     ds.set_option("stats", 1)
     try:
         cached = ds.render(p)
@@ -159,6 +176,7 @@ def test_top_of_tree_cache_does_not_change_the_image(oracle, dscenes, name):
     finally:
         ds.set_option("top_cache", 1)
         ds.set_option("stats", 0)
+        ds.set_option("fast_tree", 1)
     assert_bit_equal(cached, want, name + " top of the tree in LDS")
     assert_bit_equal(plain, want, name + " all nodes from global memory")
     for c in (c0, c1):

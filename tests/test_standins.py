@@ -52,9 +52,15 @@ def test_standins_device_matches_oracle(oracle, built, name):
     ds = dev.DeviceScene(d)
     try:
         ds.set_option("stats", 1)
-        img = ds.render(p)
+        img = ds.render(p)                                  # default: internal tree + reference-order reruns
         c = ds.counters()
         assert_bit_equal(img, want, name)
+        assert c.segments == cnt.segments
+        assert c.node_visits < cnt.inner_pops if ds.info("fast_tree") else c.node_visits == cnt.inner_pops
+        ds.set_option("fast_tree", 0)                       # the caller's (reference) tree: the oracle's own visit count
+        img = ds.render(p)
+        c = ds.counters()
+        assert_bit_equal(img, want, name + " on the reference tree")
         assert (c.segments, c.node_visits) == (cnt.segments, cnt.inner_pops)
     finally:
         ds.close()

@@ -15,6 +15,7 @@ rng = np.random.default_rng(2026)
 t0 = time.time()
 by_res = {}
 flips = 0
+reruns = 0
 for k in range(n):
     n_tris = int(rng.choice([0, 2, 3, 7, 30, 45, 60, 150, 190, 230, 400, 900, 2500, 6000]))
     n_sph = int(rng.integers(0, 6)) if n_tris else int(rng.integers(1, 6))
@@ -28,9 +29,13 @@ for k in range(n):
     ds.set_option("stats", 1)
     res = ds.info("residency")
     by_res[res] = by_res.get(res, 0) + 1
-    img = ds.render(p)
-    c = ds.counters()
+    img = ds.render(p)                       # default: scenes in global memory run on the internal tree with reference-order reruns
+    reruns += ds.info("redo_segments")
     ok = bool((img.view(np.uint32) == want.view(np.uint32)).all())
+    ds.set_option("fast_tree", 0)            # the caller's tree: counters must equal the oracle's
+    img0 = ds.render(p)
+    c = ds.counters()
+    ok = ok and bool((img0.view(np.uint32) == want.view(np.uint32)).all())
     okc = (c.paths, c.segments, c.node_visits, c.leaf_tests) == (cnt.paths, cnt.segments, cnt.inner_pops, cnt.leaf_tri + cnt.leaf_sphere)
     pr = ds.render(p, traversal=PT_TRAVERSAL_PRUNED)
     bad = int((np.abs(pr - want).max(axis=2) > 1e-4).sum())
@@ -41,4 +46,5 @@ for k in range(n):
         sys.exit(1)
     if k % 50 == 49:
         print(f"{k + 1} scenes ok, {time.time() - t0:.1f} s", flush=True)
-print(f"fuzz ok: {n} scenes, residencies {dict(sorted(by_res.items()))}, pruned traversal flipped {flips} pixels in total")
+print(f"fuzz ok: {n} scenes, residencies {dict(sorted(by_res.items()))}, pruned traversal flipped {flips} pixels in total, "
+      f"{reruns} segments rerun in reference order on the internal-tree path")

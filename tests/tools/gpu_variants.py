@@ -16,9 +16,9 @@ from pathtracer_cuda_interactive_amd import HostScene, PT_BVH_SORT_REFERENCE, st
 from pathtracer_cuda_interactive_amd import device as dev  # noqa: E402
 
 SC = os.path.join(REPO, "tests", "golden", "scenes")
-CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480, 16), "teapot": (640, 480, 16),
+CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480, 16), "teapot": (640, 480, 16), "scene4": (640, 480, 32),
            "scene1_phong": (640, 480, 16), "buddha_standin": (1280, 960, 256), "dragon_standin": (1920, 1080, 1024)}
-RESET = {"v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "blocks_per_cu": 0, "stats": 0, "lds_budget_kb": 0, "chunk": 0}
+RESET = {"v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "blocks_per_cu": 0, "stats": 0, "lds_budget_kb": 0, "chunk": 0, "fast_tree": 1}
 
 
 def main():
@@ -78,7 +78,8 @@ def main():
                 dg = [ds.info(f"diag{k}") for k in range(8)]
                 # [0] iterations [1] scheduler phases [2] lanes served [3] inner steps [4] lanes in them [5] leaf steps [6] lanes in them [7] idle lane-slots
                 line += (f" | inner steps {dg[3] / 1e6:7.1f} M x {dg[4] / max(dg[3], 1):4.1f} lanes, leaf steps {dg[5] / 1e6:6.1f} M x {dg[6] / max(dg[5], 1):4.1f} lanes,"
-                         f" sched {dg[1] / 1e6:6.1f} M x {dg[2] / max(dg[1], 1):4.1f} lanes, iters {dg[0] / 1e6:6.1f} M")
+                         f" sched {dg[1] / 1e6:6.1f} M x {dg[2] / max(dg[1], 1):4.1f} lanes, iters {dg[0] / 1e6:6.1f} M,"
+                         f" visits {c.node_visits / max(c.segments, 1):5.2f} + {c.leaf_tests / max(c.segments, 1):4.2f} per segment, rerun {ds.info('redo_segments')}")
             print(line, flush=True)
         ds.close()
 
