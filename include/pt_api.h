@@ -208,6 +208,15 @@ enum { PT_BVH_DEVICE_LBVH = 0, PT_BVH_DEVICE_SAH = 1 };
 int pt_bvh_build_device(const pt_scene_desc* desc, int method, pt_bvh_node* out_nodes, int32_t* out_root,
                         int32_t* out_depth, double* out_build_ms);
 
+/* The builder behind the library's internal tree (pt_scene_create), exposed so that the tree can be inspected, checked by
+ * a CPU oracle, or handed in as the caller's own: top-down, every cut along x, y and z considered at every node,
+ * smallest  SA(left) n_left + SA(right) n_right  wins.  Runs on the HOST (no GPU needed), deterministic.
+ * Input: the LEAF boxes of desc->nodes (one leaf per shape; the inner nodes of desc are ignored).  Output as for
+ * pt_bvh_build_device; out_build_ms = host wall time.  The tree may be deeper than the reference's 64-entry stack
+ * allows (scene.h:251) for adversarial input — *out_depth tells; pt_scene_create rejects such a tree as a CALLER's. */
+int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
+                       double* out_build_ms);
+
 /* Tuning knobs (all optional; none of them changes a bit of the rendered image):
  *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel
  *   "v2_thresh" / "v2_inner" / "v2_minw"   scheduler variant of kernel 2; 0 = automatic (by scene residency).

@@ -5,14 +5,19 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <vector>
 
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
+#include "pt_tree_sweep.h"
 #include "pt_kernels.h"
 
 using namespace ptl;
@@ -80,6 +85,7 @@ struct DeviceGuard {
 constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B nodes) are staged whole into LDS
 constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node table must fit in this many bytes of LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
+constexpr int kMinInternalTree = 16;              // primitives below which no internal tree is built (a handful of nodes either way: scene1, 4 shapes, is 6 % slower with one)
 constexpr int kProbeRays = 32768;                // validate_and_build: rays that choose between the caller's tree and the internal one
 constexpr uint64_t kDefaultScratchBytes = 8ull << 30;   // per-sample scratch cap (3 % of the 288 GB of HBM): every sample pass
                                                         // pays the launch floor once (buddha stand-in 135.6 ms in 5 passes, 130.6 in 1)
@@ -116,6 +122,9 @@ struct pt_scene {
         int depth = 0;
     } tree[2];
     bool have_fast = false;
+    DevBuf<unsigned long long> ref_path;   // per primitive: its root-to-leaf turns in the caller's tree (ties on t, pt_trace.h: ref_visits_first)
+    DevBuf<int32_t> ref_anc;         // per primitive and level: the inner node of the caller's tree there
+    int32_t ref_levels = 0;
     DevBuf<int32_t> redo_stack;      // global-memory traversal stacks of the reference-order reruns (one column per lane of the grid)
     DevBuf<DPrim> prims;
     DevBuf<DNormals> normals;
@@ -184,19 +193,25 @@ void select_tree(pt_scene* S, int which, bool fallback = false) {
     dv.ref_root_ref = S->tree[0].root_ref;
     dv.redo_cap = S->tree[0].stack_cap;
     dv.redo_stack = S->redo_stack.p;
+    dv.fixed_order = which == 1 ? 1 : 0;
+    dv.ref_path = S->ref_path.p;
+    dv.ref_anc = S->ref_anc.p;
+    dv.ref_levels = S->ref_levels;
 }
 
 struct TreeHost {
     std::vector<DNode> nodes;
     int32_t root_ref = 0;
     int depth = 1;
+    int stack_need = 1;            // stack entries a traversal can hold at once (without the sentinel)
+    std::vector<int32_t> inner_of_pool;   // caller's node pool index -> index in `nodes` (-1: a leaf)
     uint32_t top_avail = 0;
 };
 
 // pt_bvh_node pool (one node per leaf and per inner node, bvh.cuh:7-15) -> inner-only DNodes carrying both child boxes.
 // Validates the topology.  leaf_boxes (optional, [N][6]): receives every primitive's leaf box.  *nested: every node's box
 // below the root contains its children's boxes.
-int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost& out, float* leaf_boxes, bool* nested) {
+int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost& out, float* leaf_boxes, bool* nested, bool internal = false) {
     std::vector<int32_t> inner_id(num_nodes, -1);
     std::vector<DNode>& nodes = out.nodes;
     nodes.clear();
@@ -216,7 +231,31 @@ int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost
         prim_seen[rootn.prim] = 1;
         if (leaf_boxes) { std::memcpy(leaf_boxes + 6 * (size_t)rootn.prim, rootn.bmin, 12); std::memcpy(leaf_boxes + 6 * (size_t)rootn.prim + 3, rootn.bmax, 12); }
     } else {
-        // DFS pre-order: a parent and its left subtree are contiguous in memory
+        // The internal tree is traversed left child first (pt_trace.h: visit_node).  While the left subtree is being worked
+        // on, the right child waits on the stack: entries needed = max(1 + need(left), need(right)), so the child that needs
+        // less goes LEFT and the need of a node is the larger of its children's, plus one only when they are equal — the
+        // Strahler number of the tree, at most log2(leaves) + 1 whatever its depth.
+        std::vector<int32_t> need;
+        if (internal) {                                               // (the library's own tree: no validation needed here)
+            need.assign(num_nodes, 0);
+            std::vector<int32_t> pre, open;
+            open.push_back(root);
+            while (!open.empty()) {
+                const int32_t k = open.back();
+                open.pop_back();
+                pre.push_back(k);
+                for (int32_t ch : {in[k].left, in[k].right})
+                    if (in[ch].prim == -1) open.push_back(ch);
+            }
+            for (size_t k = pre.size(); k-- > 0;) {                  // parents come before their children in `pre`
+                const pt_bvh_node& nd = in[pre[k]];
+                const int32_t a = need[nd.left], b = need[nd.right];
+                need[pre[k]] = a == b ? a + 1 : std::max(a, b);
+            }
+            out.stack_need = need[root];
+        }
+        auto swapped = [&](const pt_bvh_node& nd) { return internal && need[nd.left] > need[nd.right]; };
+        // DFS pre-order: a parent and the subtree of the child it lists first are contiguous in memory
         struct Item { int32_t ref_node; int depth; };
         std::vector<Item> todo;
         todo.push_back({root, 1});
@@ -236,22 +275,37 @@ int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost
             const pt_bvh_node& ln = in[nd.left];
             const pt_bvh_node& rn = in[nd.right];
             if (it.ref_node != root && nested && !(contains(nd, ln) && contains(nd, rn))) *nested = false;
-            if (rn.prim == -1) todo.push_back({nd.right, it.depth + 1});
-            if (ln.prim == -1) todo.push_back({nd.left, it.depth + 1});
+            const bool sw = swapped(nd);
+            const int32_t first = sw ? nd.right : nd.left, second = sw ? nd.left : nd.right;
+            if (in[second].prim == -1) todo.push_back({second, it.depth + 1});
+            if (in[first].prim == -1) todo.push_back({first, it.depth + 1});
         }
         // Scenes too big for LDS: renumber so that the first kTopNodes ids are the top of the tree in breadth-first order
         // (every ray starts there; the kernel keeps a prefix of them in LDS), the rest stays in pre-order.
         if ((size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + order.size() * sizeof(DNode) > kLdsSceneLimit && order.size() > 1) {
             // only as many as fit next to the traversal stacks (make_plan)
-            const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)(std::max(depth - 1, 1) + 1) * 64u * 4u;
+            const uint32_t stack_bytes = (uint32_t)(kBlock / 64) * (uint32_t)((internal ? out.stack_need : std::max(depth - 1, 1)) + 1) * 64u * 4u;
             const size_t want = std::min<size_t>(kTopNodes, kMaxLdsBudget > stack_bytes ? (kMaxLdsBudget - stack_bytes) / sizeof(DNode) : 0);
+            // which ones: without pruning a node is visited iff the ray hits its box, so the nodes most rays visit are the ones
+            // with the largest boxes — take them in order of surface area (a child's box is never larger than its parent's,
+            // so every prefix of this list is closed under "parent of"; the kernel stages a prefix)
             std::vector<int32_t> top;
             std::vector<char> in_top(num_nodes, 0);
-            if (want) top.push_back(root);
-            for (size_t head = 0; head < top.size() && top.size() < want; head++) {
-                const pt_bvh_node& nd = in[top[head]];
+            auto area = [&](int32_t k) {
+                const pt_bvh_node& b = in[k];
+                const double x = (double)b.bmax[0] - b.bmin[0], y = (double)b.bmax[1] - b.bmin[1], z = (double)b.bmax[2] - b.bmin[2];
+                return 2.0 * (x * y + y * z + z * x);
+            };
+            typedef std::pair<double, int32_t> Cand;                  // (area, -position in pre-order): ties go to the earlier node
+            std::priority_queue<Cand> open;
+            if (want) open.push(Cand(std::numeric_limits<double>::infinity(), 0));
+            while (!open.empty() && top.size() < want) {
+                const int32_t k = order[(size_t)-open.top().second];
+                open.pop();
+                top.push_back(k);
+                const pt_bvh_node& nd = in[k];
                 for (int32_t ch : {nd.left, nd.right})
-                    if (in[ch].prim == -1 && top.size() < want) top.push_back(ch);
+                    if (in[ch].prim == -1) open.push(Cand(area(ch), -inner_id[ch]));
             }
             for (int32_t r : top) in_top[r] = 1;
             std::vector<int32_t> renum(top);
@@ -264,8 +318,10 @@ int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost
         nodes.resize(order.size());
         for (size_t k = 0; k < order.size(); k++) {
             const pt_bvh_node& nd = in[order[k]];
-            const pt_bvh_node& ln = in[nd.left];
-            const pt_bvh_node& rn = in[nd.right];
+            const bool sw = swapped(nd);
+            const int32_t li = sw ? nd.right : nd.left, ri = sw ? nd.left : nd.right;
+            const pt_bvh_node& ln = in[li];
+            const pt_bvh_node& rn = in[ri];
             DNode& o = nodes[k];
             std::memcpy(o.lmin, ln.bmin, 12); std::memcpy(o.lmax, ln.bmax, 12);
             std::memcpy(o.rmin, rn.bmin, 12); std::memcpy(o.rmax, rn.bmax, 12);
@@ -276,17 +332,19 @@ int convert_tree(const pt_bvh_node* in, int num_nodes, int root, int N, TreeHost
                     prim_seen[ch->prim] = 1;
                     if (leaf_boxes) { std::memcpy(leaf_boxes + 6 * (size_t)ch->prim, ch->bmin, 12); std::memcpy(leaf_boxes + 6 * (size_t)ch->prim + 3, ch->bmax, 12); }
                 }
-            o.left = ln.prim != -1 ? ~ln.prim : inner_id[nd.left];
-            o.right = rn.prim != -1 ? ~rn.prim : inner_id[nd.right];
+            o.left = ln.prim != -1 ? ~ln.prim : inner_id[li];
+            o.right = rn.prim != -1 ? ~rn.prim : inner_id[ri];
             o.pad0 = o.pad1 = 0;
         }
         out.root_ref = 0;
     }
     for (int i = 0; i < N; i++)
         if (!prim_seen[i]) return fail(PT_ERR_BAD_SCENE, "primitive not covered by any leaf");
-    if (depth - 1 > kMaxStack - 1)
+    if (!internal && depth - 1 > kMaxStack - 1)
         return fail(PT_ERR_BAD_SCENE, "BVH deeper than the traversal stack (reference cap 64, scene.h:251)");
     out.depth = depth;
+    out.inner_of_pool.swap(inner_id);
+    if (!internal) out.stack_need = std::max(depth - 1, 1);           // nearer child first: a pending sibling per level
     if (nodes.empty()) nodes.resize(1);   // single-primitive scene: no inner nodes; keep a dummy so pointers are valid
     return PT_OK;
 }
@@ -359,22 +417,21 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     if (trc) return trc;
     TreeHost fast;
     bool have_fast = false;
-    const bool small_scene = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref.nodes.size() * sizeof(DNode) + 1024 <= kLdsSceneLimit / 2;
-    if (N >= 2 && nested && !small_scene) {        // (scenes far below the LDS limit never leave LDS: no second tree for them)
+    if (N >= kMinInternalTree && nested) {
         // A leaf is tested by the reference iff the ray hits every box on its way down (scene.h:278-297, no pruning).  The slab
         // test is monotone in the box (rounding is), so where every box contains its children's that is: iff it hits the LEAF's
         // own box — whatever the tree above it.  `nested` says the caller's tree is of that kind; then any tree over the same
         // leaf boxes tests the same leaves, and only the ORDER of the tests (ties on t, scene.h:270) still depends on the tree.
-        std::vector<pt_bvh_node> fnodes((size_t)d->num_nodes);
-        int froot = 0, fdepth = 0;
-        // LDS-resident scenes: one level more than the caller's tree at most, so that the traversal stacks keep their size
-        // (cbox: 26.5 KB per block = 6 resident blocks; one more stack entry pair would cost a block per CU).  Larger scenes:
-        // the builder's default of ceil(log2 N) + 5 levels.
-        const bool small = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref.nodes.size() * sizeof(DNode) <= kLdsSceneLimit;
-        const int cap = small ? ref.depth + 1 : 0;      // (used only with force_global)
-        if (pt_bvh_build_from_boxes(leaf_boxes.data(), N, PT_BVH_DEVICE_SAH, fnodes.data(), &froot, &fdepth, cap) == PT_OK) {
+        // The tree: all cuts along x, y and z at every node (pt_tree_sweep.h), as deep as it likes — traversed left child
+        // first, its stack need is its Strahler number, not its depth (convert_tree).
+        bool finite = true;
+        for (size_t k = 0; k < leaf_boxes.size() && finite; k++) finite = std::isfinite(leaf_boxes[k]);
+        if (finite) {
+            std::vector<pt_bvh_node> fnodes;
+            int32_t froot = 0, fdepth = 0;
+            pts::build_sweep_tree(leaf_boxes.data(), N, fnodes, &froot, &fdepth);
             bool fnested = true;
-            have_fast = convert_tree(fnodes.data(), d->num_nodes, froot, N, fast, nullptr, &fnested) == PT_OK && fnested;
+            have_fast = convert_tree(fnodes.data(), d->num_nodes, froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
         }
     }
     const TreeHost* hosts[2] = {&ref, have_fast ? &fast : nullptr};
@@ -422,7 +479,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         HIP_TRY(hipMemcpy(T.nodes.p, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
         T.num_nodes = (int32_t)nodes.size();
         T.root_ref = hosts[t]->root_ref;
-        T.stack_cap = std::max(hosts[t]->depth - 1, 1) + 1;     // + the kDone sentinel at the bottom
+        T.stack_cap = hosts[t]->stack_need + 1;                 // + the kDone sentinel at the bottom
         T.top_avail = hosts[t]->top_avail;
         T.depth = hosts[t]->depth;
     }
@@ -470,6 +527,35 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             S->tree[1].nodes_oct.release();
             S->tree[1].have_oct = false;
         }
+    }
+    if (S->have_fast) {
+        // what settles ties on t in the caller's visit order: every primitive's path from the caller's root (turn bits) and
+        // the inner nodes along it.  (Depth <= 64 levels of leaves and inner nodes: at most 63 turns.)
+        const int levels = std::max(ref.depth - 1, 1);
+        std::vector<unsigned long long> path(N, 0ull);
+        std::vector<int32_t> anc((size_t)N * levels, 0);
+        struct Walk { int32_t node; int32_t level; unsigned long long turns; };
+        std::vector<Walk> todo;
+        std::vector<int32_t> trail(levels, 0);
+        todo.push_back({d->root, 0, 0ull});
+        while (!todo.empty()) {
+            const Walk w = todo.back();
+            todo.pop_back();
+            const pt_bvh_node& nd = d->nodes[w.node];
+            if (nd.prim != -1) {
+                path[nd.prim] = w.turns;
+                std::memcpy(&anc[(size_t)nd.prim * levels], trail.data(), (size_t)w.level * sizeof(int32_t));
+                continue;
+            }
+            trail[w.level] = ref.inner_of_pool[w.node];
+            // depth-first, left subtree first: `trail` below w.level is still this node's path when its right child is taken up
+            todo.push_back({nd.right, w.level + 1, w.turns | (1ull << w.level)});
+            todo.push_back({nd.left, w.level + 1, w.turns});
+        }
+        if ((rc = S->ref_path.ensure(path.size())) || (rc = S->ref_anc.ensure(anc.size()))) return rc;
+        HIP_TRY(hipMemcpy(S->ref_path.p, path.data(), path.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S->ref_anc.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        S->ref_levels = levels;
     }
     select_tree(S, 0);
     S->scene_bytes = (uint32_t)std::min<size_t>(
@@ -569,13 +655,10 @@ TraceFn pick_kernel_nee(int res, bool stats, int spec) {
 }
 
 // Residency the next launch will use (see make_plan).
-// The tree an exact / pruned render traverses: the internal surface-area-cost tree for exact traversal on the default kernel
-// (with reference-order reruns, see launch_render), the caller's tree otherwise.
-// Scenes that are staged whole in LDS stay on the caller's tree: there the reference's tree is as good as any (cbox: 14.76
-// inner visits per segment against 15.1 on a surface-area tree of the same depth; a deeper one costs a resident block).
+// The tree an exact / pruned render traverses: the internal tree for exact traversal on the default kernel (with
+// reference-order reruns, see launch_render) where scene creation kept one, the caller's tree otherwise.
 int which_tree(const pt_scene* S, int traversal) {
-    const bool global_scene = S->opt_force_global || S->scene_bytes > kLdsSceneLimit;
-    return (S->have_fast && S->opt_fast_tree && S->opt_kernel == 2 && traversal == PT_TRAVERSAL_EXACT && global_scene) ? 1 : 0;
+    return (S->have_fast && S->opt_fast_tree && S->opt_kernel == 2 && traversal == PT_TRAVERSAL_EXACT) ? 1 : 0;
 }
 
 int scene_residency(const pt_scene* S, int which = 0) {
@@ -716,7 +799,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         const size_t lanes = (size_t)S->num_cus * 8 * kBlock;
         if ((rc = S->redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
     }
-    select_tree(S, which, which == 1);
+    select_tree(S, which, which == 1 && S->opt_fast_tree != 2);   // (fast_tree = 2: timing experiment without reruns — NOT exact)
     float* accum = mode == 2 ? out_dev : S->accum.p;
     for (int pass = 0; pass < n_pass; pass++) {
         const int s0 = pass * (int)spp_pass;
@@ -942,9 +1025,11 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     }
     else if (k == "num_cus") *value = S->num_cus;
     else if (k == "bvh_depth") *value = S->tree[0].depth;
+    else if (k == "stack_entries") *value = S->tree[which_tree(S, PT_TRAVERSAL_EXACT)].stack_cap;   // per lane, sentinel included
     else if (k == "fast_tree") *value = S->have_fast ? 1 : 0;             // an internal tree exists (the caller's tree is nested)
     else if (k == "debug_reruns") *value = S->info_debug_reruns;          // rays the last pt_debug_intersect reran in reference order
     else if (k == "fast_tree_cost_permille") *value = S->fast_cost_permille;   // summed inner-box area, internal tree / caller's tree x 1000 (0: none built)
+    else if (k == "fast_tree_on") *value = which_tree(S, PT_TRAVERSAL_EXACT);    // ... and the next exact render traverses it
     else if (k == "fast_tree_depth") *value = S->have_fast ? S->tree[1].depth : 0;
     else if (k == "scene_bytes") *value = S->scene_bytes;
     else if (k == "num_inner_nodes") *value = S->tree[0].num_nodes;
@@ -1014,6 +1099,35 @@ int pt_debug_math_host(int op, const float* x, const float* y, float* out0, floa
             out1[k] = ptm::pcg_float(r);
         }
     }
+    return PT_OK;
+}
+
+int pt_bvh_build_sweep(const pt_scene_desc* d, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth, double* out_build_ms) {
+    if (!d || !out_nodes || !out_root) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    const int N = d->num_shapes;
+    if (N <= 0 || !d->nodes || d->num_nodes != 2 * N - 1) return fail(PT_ERR_BAD_SCENE, "needs the leaf boxes of a 2*num_shapes-1 node pool");
+    std::vector<float> boxes((size_t)N * 6);
+    std::vector<char> seen(N, 0);
+    for (int k = 0; k < d->num_nodes; k++) {
+        const pt_bvh_node& nd = d->nodes[k];
+        if (nd.prim == -1) continue;
+        if (nd.prim < 0 || nd.prim >= N || seen[nd.prim]) return fail(PT_ERR_BAD_SCENE, "leaves must cover every shape exactly once");
+        seen[nd.prim] = 1;
+        std::memcpy(&boxes[(size_t)nd.prim * 6], nd.bmin, 12);
+        std::memcpy(&boxes[(size_t)nd.prim * 6 + 3], nd.bmax, 12);
+    }
+    for (int i = 0; i < N; i++)
+        if (!seen[i]) return fail(PT_ERR_BAD_SCENE, "leaves must cover every shape exactly once");
+    for (float v : boxes)
+        if (!std::isfinite(v)) return fail(PT_ERR_BAD_SCENE, "leaf box is not finite");
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<pt_bvh_node> nodes;
+    int32_t root = 0, depth = 0;
+    pts::build_sweep_tree(boxes.data(), N, nodes, &root, &depth);
+    std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(pt_bvh_node));
+    *out_root = root;
+    if (out_depth) *out_depth = depth;
+    if (out_build_ms) *out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
 }
 

@@ -311,7 +311,7 @@ struct Dev {
 
 // Everything after the primitive boxes: Morton order, range tree, hierarchy, depth, copy back.  d_boxes: n boxes on the device.
 int bvh_build_core(const Box* d_boxes, int n, int method, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
-                   hipEvent_t e0, hipEvent_t e1, double* out_build_ms, int depth_cap = 0) {
+                   hipEvent_t e0, hipEvent_t e1, double* out_build_ms) {
     int P = 1;
     while (P < n) P <<= 1;
     const int n_nodes = 2 * n - 1;
@@ -355,7 +355,7 @@ int bvh_build_core(const Box* d_boxes, int n, int method, pt_bvh_node* out_nodes
         // little (bunny: 22.6 inner visits per segment uncapped at depth 28, 23.3 capped at 24, 32.1 at 22)
         int lg = 0;
         while ((1 << lg) < n) lg++;
-        const int max_depth = depth_cap > 0 ? std::min(48, std::max(lg + 1, depth_cap)) : std::min(48, std::max(8, lg + 5));
+        const int max_depth = std::min(48, std::max(8, lg + 5));
         for (int depth = 1; depth < max_depth; depth++) {
             hipLaunchKernelGGL(sah_cost_kernel, G(n), dim3(B), 0, nullptr, d_sp.p, d_tree.p, P, n, d_best.p);
             HIPB(hipMemsetAsync(d_misc.p + 1, 0, sizeof(int), nullptr));
@@ -391,22 +391,6 @@ struct EvGuard {
 };
 
 }  // namespace
-
-// Internal entry for pt_scene_create: the hierarchy over GIVEN primitive boxes (n x {min xyz, max xyz}, host memory) — the
-// leaf boxes of the caller's own tree, so that both trees test the very same boxes before a primitive.
-int pt_bvh_build_from_boxes(const float* boxes, int n, int method, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
-                            int depth_cap) {
-    if (n < 2) return pt_fail(PT_ERR_INVALID_ARG, "needs at least two primitives");
-    Dev<Box> d_boxes;
-    int rc;
-    if ((rc = d_boxes.alloc(n))) return rc;
-    HIPB(hipMemcpy(d_boxes.p, boxes, (size_t)n * sizeof(Box), hipMemcpyHostToDevice));
-    EvGuard evg;
-    HIPB(hipEventCreate(&evg.a));
-    HIPB(hipEventCreate(&evg.b));
-    HIPB(hipEventRecord(evg.a, nullptr));
-    return bvh_build_core(d_boxes.p, n, method, out_nodes, out_root, out_depth, evg.a, evg.b, nullptr, depth_cap);
-}
 
 extern "C" int pt_bvh_build_device(const pt_scene_desc* d, int method, pt_bvh_node* out_nodes, int32_t* out_root,
                                    int32_t* out_depth, double* out_build_ms) {

@@ -185,6 +185,8 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
     sv.lights = scn.lights;
     sv.num_emission = scn.num_emission;
     sv.root_ref = scn.root_ref;
+    sv.fixed_order = scn.fixed_order;
+    sv.ref_nodes = scn.ref_nodes; sv.ref_path = scn.ref_path; sv.ref_anc = scn.ref_anc; sv.ref_levels = scn.ref_levels;
     sv.bg = ptm::mk(scn.bg[0], scn.bg[1], scn.bg[2]);
     return sv;
 }
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
     const bool fbk = scn.fallback != 0;                       // wave-uniform
     ptd::SceneView sv_ref = sv;
     sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref; sv_ref.node_stride = sizeof(DNode);
-    sv_ref.oct_stride = 0; sv_ref.top_nodes = nullptr; sv_ref.top_count = 0;
+    sv_ref.oct_stride = 0; sv_ref.top_nodes = nullptr; sv_ref.top_count = 0; sv_ref.fixed_order = 0;
     int32_t* redo_stk = scn.redo_stack + ((size_t)(blockIdx.x * (kBlock / 64) + wave) * (size_t)scn.redo_cap) * 64 + lane;
     uint32_t n_redo = 0;
     // next-event estimation: the lane is tracing the shadow ray of its light sample; what it resumes with afterwards
@@ -568,7 +570,8 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     sv.materials = scn.materials; sv.emission = scn.emission; sv.lights = scn.lights;
     sv.top_nodes = nullptr; sv.top_count = 0;
     sv.node_stride = sizeof(DNode);
-    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
+    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref; sv.fixed_order = scn.fixed_order;
+    sv.ref_nodes = scn.ref_nodes; sv.ref_path = scn.ref_path; sv.ref_anc = scn.ref_anc; sv.ref_levels = scn.ref_levels;
     sv.bg = ptm::mk(0, 0, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cap = scn.fallback && scn.redo_cap > scn.stack_cap ? scn.redo_cap : scn.stack_cap;   // one column serves both trees
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     ptd::Hit h;
     if (!PRUNE && scn.fallback) {                         // internal tree, reference-order rerun where the order matters
         ptd::SceneView sv_ref = sv;
-        sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref;
+        sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref; sv_ref.fixed_order = 0;
         bool rerun;
         h = ptd::intersect_any_tree(sv, sv_ref, r, stk, rerun);
         if (rerun) atomicAdd(reruns, 1);
@@ -607,7 +610,8 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(SceneDev scn, unsigned lo
     sv.materials = scn.materials; sv.emission = scn.emission; sv.lights = scn.lights;
     sv.top_nodes = nullptr; sv.top_count = 0;
     sv.node_stride = sizeof(DNode);
-    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref;
+    sv.num_emission = scn.num_emission; sv.root_ref = scn.root_ref; sv.fixed_order = scn.fixed_order;
+    sv.ref_nodes = scn.ref_nodes; sv.ref_path = scn.ref_path; sv.ref_anc = scn.ref_anc; sv.ref_levels = scn.ref_levels;
     sv.bg = ptm::mk(0, 0, 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* stk = reinterpret_cast<int32_t*>(smem) + (size_t)wave * scn.stack_cap * 64 + lane;

@@ -79,6 +79,11 @@ struct SceneDev {
     int32_t ref_root_ref;
     int32_t redo_cap;               // stack entries per lane of a rerun
     int32_t* redo_stack;            // [waves of the grid][redo_cap][64]
+    int32_t fixed_order;            // `nodes` is the internal tree: left child first, stack_cap counts on it
+    // ties on t are settled in the caller's tree's visit order (pt_trace.h: ref_visits_first)
+    const unsigned long long* ref_path;   // [num_prims] turns from the root to the primitive's leaf in the caller's tree
+    const int32_t* ref_anc;         // [num_prims][ref_levels] inner nodes of the caller's tree along that path
+    int32_t ref_levels;
 };
 
 // Division of a number below 2^30 by a launch constant: q = (n * mul) >> shift, exact for every n < 2^30

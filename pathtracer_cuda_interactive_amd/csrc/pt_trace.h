@@ -52,6 +52,13 @@ struct SceneView {
     const DLight* lights;   // global memory (next-event estimation)
     int32_t num_emission;
     int32_t root_ref;
+    // the library's internal tree: the LEFT child first, always (see visit_node; the traversal stack is sized for that order)
+    int32_t fixed_order;
+    // ... and what settles a tie on t the reference's way without leaving that tree (ref_visits_first)
+    const DNode* ref_nodes;           // the caller's tree, plain layout, global memory
+    const unsigned long long* ref_path;   // [prim] turns from the root to the primitive's leaf, bit k = level k goes right
+    const int32_t* ref_anc;           // [prim * ref_levels + k] the inner node of the caller's tree at level k of that path
+    int32_t ref_levels;
     V3 bg;
 };
 
@@ -100,9 +107,28 @@ __device__ __forceinline__ void trav_begin(const SceneView& sv, const Ray& ray, 
 // (Measured and rejected in round 2, all bit-exact: separate step kinds for LDS-served / global-memory / leaf visits,
 // +39..+111 % time; a gathered fetch — node ids compacted through LDS, quad-coalesced LDS-DMA into per-wave tiles —
 // +30..+50 %; child references loaded as a dwordx2, +1.5..+4 %: profiles/r02_tune_round34..37_*.log)
+// Entry / exit distances of the two child boxes of a plain-layout node (a, b, c = its first three 16-B pieces): bbox.cuh:36-55.
+__device__ __forceinline__ void slab_distances(const float4 a, const float4 b, const float4 c, const V3& o, const V3& inv,
+                                               float& ltn, float& ltf, float& rtn, float& rtf) {
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    // left box
+    float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
+    float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
+    float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
+    ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
+    ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
+    // right box
+    float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
+    float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
+    float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
+    rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
+    rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
+}
+
 // Everything of an inner visit after the node has been fetched (a, b, c, d = the node's four 16-B pieces).
 template <bool PRUNE, bool OCT, class STK>
-__device__ __forceinline__ void visit_node(const float4 a, const float4 b, const float4 c, const float4 d, const V3& o, Trav& t, STK* stk) {
+__device__ __forceinline__ void visit_node(const float4 a, const float4 b, const float4 c, const float4 d, const V3& o, Trav& t, STK* stk,
+                                           const bool fixed_order) {
     const V3 inv = t.inv;
     float ltn, ltf, rtn, rtf;
     if (OCT) {
@@ -111,19 +137,7 @@ __device__ __forceinline__ void visit_node(const float4 a, const float4 b, const
         rtn = fmax2(fmax2((b.z - o.x) * inv.x, (b.w - o.y) * inv.y), (c.x - o.z) * inv.z);
         rtf = fmin2(fmin2((c.y - o.x) * inv.x, (c.z - o.y) * inv.y), (c.w - o.z) * inv.z);
     } else {
-        const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
-        // bbox.cuh:36-55 for the left box
-        float l0x = (a.x - o.x) * inv.x, l1x = (a.w - o.x) * inv.x;
-        float l0y = (a.y - o.y) * inv.y, l1y = (b.x - o.y) * inv.y;
-        float l0z = (a.z - o.z) * inv.z, l1z = (b.y - o.z) * inv.z;
-        ltn = fmax2(fmax2(sx ? l1x : l0x, sy ? l1y : l0y), sz ? l1z : l0z);
-        ltf = fmin2(fmin2(sx ? l0x : l1x, sy ? l0y : l1y), sz ? l0z : l1z);
-        // right box
-        float r0x = (b.z - o.x) * inv.x, r1x = (c.y - o.x) * inv.x;
-        float r0y = (b.w - o.y) * inv.y, r1y = (c.z - o.y) * inv.y;
-        float r0z = (c.x - o.z) * inv.z, r1z = (c.w - o.z) * inv.z;
-        rtn = fmax2(fmax2(sx ? r1x : r0x, sy ? r1y : r0y), sz ? r1z : r0z);
-        rtf = fmin2(fmin2(sx ? r0x : r1x, sy ? r0y : r1y), sz ? r0z : r1z);
+        slab_distances(a, b, c, o, inv, ltn, ltf, rtn, rtf);
     }
     bool hl = ltf >= fmax2(0.0f, ltn);
     bool hr = rtf >= fmax2(0.0f, rtn);
@@ -140,7 +154,11 @@ __device__ __forceinline__ void visit_node(const float4 a, const float4 b, const
     // scene.h:281-297: both hit -> visit the nearer box first (on a tie the right one) and keep the other on the
     // stack; one hit -> descend into it; none -> pop.  The stack bottom holds a kDone sentinel (trav_begin), so a
     // pop needs no emptiness test.  Written with selects so that only the push and the pop are masked regions.
-    const bool left_first = ltn < rtn;
+    // fixed_order (wave-uniform; the internal tree only, where exact traversal may visit in ANY order — rays whose answer
+    // depends on it are rerun on the caller's tree): left first.  The builder puts the child that needs the SHALLOWER stack
+    // on the left, which bounds the stack by the tree's Strahler number, <= log2(leaves) + 1, however deep the tree is
+    // (pt_api.hip: convert_tree).
+    const bool left_first = fixed_order || ltn < rtn;
     const bool both = hl && hr;
     const int32_t next = (hl && (!hr || left_first)) ? L : R;
     if (both) {
@@ -180,7 +198,25 @@ __device__ __forceinline__ void inner_step(const SceneView& sv, const V3& o, Tra
         c = ld4(nd, 2);    // rmin.z   rmax.xyz    (OCT: rnear.z  rfar.xyz)
         d = ld4(nd, 3);    // left right - -
     }
-    visit_node<PRUNE, OCT, STK>(a, b, c, d, o, t, stk);
+    visit_node<PRUNE, OCT, STK>(a, b, c, d, o, t, stk, sv.fixed_order != 0);
+}
+
+// Two primitives, both tested by this ray, give the same t: the reference keeps the one it VISITS first (scene.h:270, strict <).
+// Its visit order is decided at one place — the lowest node of the caller's tree that has both below it: there both child
+// boxes are hit (every box above a tested leaf is), and the reference descends into the nearer one first, on equal entry
+// distances the right one (scene.h:281-297 as restated in visit_node).  So: the level where the two root-to-leaf paths part
+// (ref_path), the node there (ref_anc), its two entry distances for this ray — the same arithmetic on the same operands as a
+// visit of that node.  True iff `b` comes before `a`.
+__device__ __forceinline__ bool ref_visits_first(const SceneView& sv, const V3& o, const V3& inv, const int32_t a, const int32_t b) {
+    const unsigned long long pa = sv.ref_path[a], pb = sv.ref_path[b];
+    const int level = __builtin_ctzll(pa ^ pb);                 // distinct leaves: neither path is a prefix of the other
+    const int32_t node = sv.ref_anc[(size_t)a * (size_t)sv.ref_levels + level];
+    const DNode* nd = sv.ref_nodes + node;
+    float ltn, ltf, rtn, rtf;
+    slab_distances(ld4(nd, 0), ld4(nd, 1), ld4(nd, 2), o, inv, ltn, ltf, rtn, rtf);
+    const bool left_first = ltn < rtn;
+    const bool b_left = ((pb >> level) & 1ull) == 0ull;
+    return b_left == left_first;
 }
 
 // One leaf visit (requires t.cur < 0 && t.cur != done_value<STK>()): primitive test, keep the hit if strictly closer, pop.
@@ -211,8 +247,9 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             const float v = dot(ray.dir, s2) * inv_divisor;
             const float tt = dot(e2, s2) * inv_divisor;
             if (tt > ray.tnear && tt < ray.tfar && u >= 0.0f && v >= 0.0f && u + v <= 1.0f) {
-                if (ties && tt == t.best.t) t.redo = true;          // the reference keeps the first one VISITED: its order decides
-                if (tt < t.best.t) { t.best.t = tt; t.best.u = u; t.best.v = v; t.best.prim = prim; }
+                bool take = tt < t.best.t;
+                if (ties && tt == t.best.t && t.best.prim >= 0) take = ref_visits_first(sv, o, t.inv, t.best.prim, prim);
+                if (take) { t.best.t = tt; t.best.u = u; t.best.v = v; t.best.prim = prim; }
             }
         }
     } else {
@@ -242,8 +279,9 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             float tt = t0;
             if (t1 >= ray.tnear && t1 < ray.tfar && tt < ray.tnear) tt = t1;
             if (tt >= ray.tnear && tt < ray.tfar) {
-                if (ties && tt == t.best.t) t.redo = true;
-                if (tt < t.best.t) { t.best.t = tt; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = prim; }
+                bool take = tt < t.best.t;
+                if (ties && tt == t.best.t && t.best.prim >= 0) take = ref_visits_first(sv, o, t.inv, t.best.prim, prim);
+                if (take) { t.best.t = tt; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = prim; }
             }
         }
     }

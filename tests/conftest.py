@@ -60,6 +60,27 @@ def assert_bit_equal(a, b, what=""):
                              f"{a[tuple(idx)]!r} vs {b[tuple(idx)]!r}; max abs diff {np.nanmax(np.abs(a - b)):.3e}")
 
 
+def assert_work_counters(ds, c, cnt, oracle, d, p, what=""):
+    """Device work counters of an EXACT render against the oracle's.  Paths and segments always agree.  Node visits and
+    primitive tests agree with the oracle ON THE TREE THE DEVICE TRAVERSED: the caller's, or — where scene creation kept the
+    library's internal tree (info fast_tree) and the option is on — that tree, which pt_bvh_build_sweep reproduces for the
+    oracle (visit COUNTS do not depend on the visit order: exact traversal never prunes).  Rays with a zero direction
+    component leave the internal tree at once and are rerun on the caller's (info redo_segments): they are the slack."""
+    assert (c.paths, c.segments) == (cnt.paths, cnt.segments), what
+    from pathtracer_cuda_interactive_amd import device as dev
+    if ds.info("fast_tree") and ds.info("fast_tree_on"):
+        d_int, _ = dev.build_bvh_sweep(d)
+        _, cnt_int = oracle.render(d_int, p)
+        slack = ds.info("redo_segments")
+        assert c.node_visits < cnt.inner_pops, what
+        assert abs(c.node_visits - cnt_int.inner_pops) <= 256 * slack, (what, c.node_visits, cnt_int.inner_pops, slack)
+        assert abs(c.leaf_tests - (cnt.leaf_tri + cnt.leaf_sphere)) <= 256 * slack, what
+        # the same leaves are tested on any tree — by every ray the argument covers (all of them when nothing was rerun)
+        assert abs(cnt_int.leaf_tri + cnt_int.leaf_sphere - (cnt.leaf_tri + cnt.leaf_sphere)) <= 256 * slack, (what, slack)
+    else:
+        assert c.node_visits == cnt.inner_pops and c.leaf_tests == cnt.leaf_tri + cnt.leaf_sphere, what
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_binding

@@ -3,15 +3,16 @@
 The reference's intersect() (scene.h:246-301) never prunes: a leaf is tested iff the ray passes the box test of every node
 on the way down.  Where every box contains its children's boxes the slab test is monotone in the box, so that is: iff the
 ray hits the leaf's OWN box — whatever tree sits above it.  The library therefore traverses scenes that live in global
-memory on a surface-area tree of its own over the same leaf boxes and reruns, in reference order on the caller's tree, the
-rays whose answer depends on the visit order: two candidates at equal t (the first VISITED wins, scene.h:270) and rays
-with a zero direction component (1/d infinite).  The result must equal the oracle ON THE CALLER'S TREE bit for bit; these
-tests aim at exactly the cases the argument has to cover."""
+memory on a surface-area tree of its own over the same leaf boxes.  What still depends on the visit order is handled the
+reference's way: two candidates at equal t (the first VISITED wins, scene.h:270) are ordered by one box test at the node of
+the caller's tree where their paths part, and rays with a zero direction component (1/d infinite, outside the argument)
+are rerun on the caller's tree.  The result must equal the oracle ON THE CALLER'S TREE bit for bit; these tests aim at
+exactly the cases the argument has to cover."""
 import ctypes as C
 
 import numpy as np
 import pytest
-from conftest import assert_bit_equal, load_scene, random_scene
+from conftest import assert_bit_equal, assert_work_counters, load_scene, random_scene
 
 from pathtracer_cuda_interactive_amd import PT_MAT_DIFFUSE, PT_TRAVERSAL_EXACT
 from pathtracer_cuda_interactive_amd import device as dev
@@ -139,8 +140,13 @@ def test_render_with_ties_equals_the_oracle_on_the_callers_tree(oracle, seed):
     assert_bit_equal(img, want, "internal tree, ties")
     assert_bit_equal(img_plain, want, "internal tree, ties, no top-of-tree cache")
     assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
-    assert reruns > 100, reruns                    # rays through the doubled triangles
-    assert c.node_visits < cnt.inner_pops          # and still far fewer boxes than the caller's tree needs
+    assert c.node_visits < cnt.inner_pops          # far fewer boxes than the caller's tree needs
+    # and the ties are real: the oracle on the internal tree's own twin (same builder, its own visit order) sees other
+    # primitives win in many pixels — the device, traversing that tree, still reproduces the caller's order
+    d_sweep, _ = dev.build_bvh_sweep(d)
+    other, _ = oracle.render(d_sweep, p)
+    assert int((other != want).any(axis=2).sum()) > 50
+    assert reruns < cnt.segments // 1000           # settled in place (ref_visits_first), not by rerunning the ray
 
 
 @pytest.mark.gpu
@@ -199,8 +205,10 @@ def test_root_box_is_never_tested_so_it_may_be_anything(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,w,h,spp", [("bunny", 160, 120, 4), ("teapot", 128, 96, 4)])
-def test_internal_tree_is_the_default_for_scenes_in_global_memory_and_off_for_lds_scenes(oracle, name, w, h, spp):
+@pytest.mark.parametrize("name,w,h,spp,internal", [("bunny", 160, 120, 4, True), ("teapot", 128, 96, 4, True), ("cbox", 128, 96, 8, True),
+                                                   ("scene4", 96, 72, 8, True), ("scene1", 96, 72, 8, False)])
+def test_internal_tree_is_the_default_where_it_pays(oracle, name, w, h, spp, internal):
+    """Meshes in global memory and LDS-resident scenes alike; a scene of a handful of primitives keeps the caller's tree."""
     hs, d = load_scene(name)
     p = hs.render_params(w, h, spp, seed=5)
     want, cnt = oracle.render(d, p)
@@ -209,15 +217,14 @@ def test_internal_tree_is_the_default_for_scenes_in_global_memory_and_off_for_ld
         ds.set_option("stats", 1)
         img = ds.render(p)
         c = ds.counters()
-        lds_scene = ds.info("lds_scene")
-        have = ds.info("fast_tree")
+        assert ds.info("fast_tree") == ds.info("fast_tree_on") == (1 if internal else 0)
+        assert_bit_equal(img, want, name)
+        assert_work_counters(ds, c, cnt, oracle, d, p, name)
+        if internal:
+            assert 0 < ds.info("fast_tree_cost_permille") < 900
+            assert ds.info("stack_entries") <= ds.info("fast_tree_depth")       # Strahler number, not depth
     finally:
         ds.close()
-    assert_bit_equal(img, want, name)
-    if lds_scene:          # staged whole in LDS: the caller's tree, the oracle's own visit count
-        assert c.node_visits == cnt.inner_pops
-    else:
-        assert have == 1 and c.node_visits < 0.7 * cnt.inner_pops
 
 
 @pytest.mark.gpu

@@ -6,7 +6,7 @@ import os
 
 import numpy as np
 import pytest
-from conftest import GOLDEN, assert_bit_equal, load_scene, random_scene
+from conftest import assert_work_counters, GOLDEN, assert_bit_equal, load_scene, random_scene
 from test_golden_vectors import parse_image_name
 
 from pathtracer_cuda_interactive_amd import (PT_ERR_BAD_SCENE, PT_ERR_INVALID_ARG, PT_ERR_UNSUPPORTED, PT_MAT_DIFFUSE,
@@ -71,7 +71,7 @@ def test_scheduler_variants_are_bit_identical(oracle, dscenes, thresh, inner, mi
         for k, v in (("v2_thresh", 0), ("v2_inner", 0), ("v2_minw", 0), ("stats", 0)):     # 0 = automatic choice
             ds.set_option(k, v)
     assert_bit_equal(img, want, f"T{thresh} I{inner} W{minw}")
-    assert (c.paths, c.segments, c.node_visits) == (cnt.paths, cnt.segments, cnt.inner_pops)
+    assert_work_counters(ds, c, cnt, oracle, d, p)
     ds.set_option("v2_thresh", 17)
     with pytest.raises(PtError) as e:            # not compiled in
         ds.render(p)
@@ -91,21 +91,15 @@ def test_device_matches_live_oracle(oracle, dscenes, name, w, h, spp):
     c = ds.counters()
     assert_bit_equal(img, want, name)
     assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
-    if ds.info("fast_tree") and ds.info("residency") in (0, 3):
-        # Scenes in global memory are traversed on the internal surface-area tree: the SAME leaves are tested (a leaf is
-        # tested iff the ray hits its own box, whatever the tree above it), in fewer node visits; the few rays whose closest
-        # hit depends on the visit order are rerun in reference order, which the leaf counter sees as extra tests.
-        assert c.node_visits < cnt.inner_pops
-        assert 0 <= c.leaf_tests - (cnt.leaf_tri + cnt.leaf_sphere) <= 64 * (1 + ds.info("redo_segments"))
-        ds.set_option("fast_tree", 0)
+    assert_work_counters(ds, c, cnt, oracle, d, p, name)
+    if ds.info("fast_tree"):
+        ds.set_option("fast_tree", 0)               # the caller's tree: the oracle's own visit counts
         img = ds.render(p, traversal=PT_TRAVERSAL_EXACT)
         c = ds.counters()
-        ds.set_option("fast_tree", 1)
         assert_bit_equal(img, want, name + " on the caller's tree")
+        assert_work_counters(ds, c, cnt, oracle, d, p, name + " on the caller's tree")
+        ds.set_option("fast_tree", 1)
     ds.set_option("stats", 0)
-    # on the caller's tree the work counters agree with the oracle's: same node visits, same primitive tests
-    assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
-    assert c.node_visits == cnt.inner_pops and c.leaf_tests == cnt.leaf_tri + cnt.leaf_sphere
     # pruned traversal is NOT guaranteed bit-exact (a triangle's t can round below its box's entry distance: DESIGN.md §6):
     # a legitimate rounding flip may move a pixel by one path's radiance / spp, so this is a tolerance, not a bit test
     img2 = ds.render(p, traversal=PT_TRAVERSAL_PRUNED)
