@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="cbox", choices=sorted(WORKLOADS))
     ap.add_argument("--traversal", default="exact", choices=["exact", "pruned"])
+    ap.add_argument("--tree", default="internal", choices=["internal", "caller"],
+                    help="exact traversal: the library's internal tree over the caller's leaf boxes (default; bit-identical "
+                         "results) or the caller's (reference median-split) tree itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stub-renderer", action="store_true",
                     help="TEST HOOK: run the multi-rank control flow on CPU (gloo) with a renderer that renders nothing")
@@ -274,6 +277,8 @@ def main():
         return progressive_mode(args, hs, desc, wl)
 
     R = StubRenderer(desc, hs) if stub else D.ShardedRenderer(desc)
+    if not stub and args.tree == "caller":
+        R.scene.set_option("fast_tree", 0)
     kernel_ms, resolve_ms, segs, paths = [], [], [], []
 
     def step(record):
@@ -351,6 +356,10 @@ def main():
                        "grid": int(R.scene.info("grid")), "blocks_per_cu": int(R.scene.info("blocks_per_cu")),
                        "blocks_per_cu_occupancy_limit": int(R.scene.info("occupancy")),
                        "vgprs": int(R.scene.info("vgprs_pruned" if args.traversal == "pruned" else "vgprs")),
+                       # exact traversal runs on the library's internal tree where scene creation kept one: same leaves tested,
+                       # same closest hits (ties in the caller's visit order), fewer inner visits; "caller" = --tree caller
+                       "tree": ("stub" if stub else "internal" if (args.traversal == "exact" and R.scene.info("fast_tree_on")) else "caller"),
+                       "stack_entries": 0 if stub else int(R.scene.info("stack_entries")),
                        "frame_mean": round(float(frame.mean().item()), 6)},
             # SURVEY §8d's fields, exactly as defined there: ALGORITHMIC bytes of the reference layout per second against the HBM
             # peak (can exceed 1: those bytes are served by LDS / L1 / L2, not by HBM).  `physical` names the bound that really

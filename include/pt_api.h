@@ -224,8 +224,15 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  *                   rounds*100 + inner*10 + leaf steps (162 = 6 inner + 2 leaf steps).  Only compiled-in variants are
  *                   accepted (PT_ERR_INVALID_ARG otherwise); every variant renders the same bits.
  *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
- *   "top_cache"     1 (default) scenes read from global memory keep the top levels of the BVH in LDS, 0 = all from memory
- *   "lds_budget_kb" LDS per block for traversal stacks + that cache (0 = 31: 5 resident blocks per CU)
+ *   "fast_tree"     1 (default) exact traversal on the library's INTERNAL tree where pt_scene_create kept one, 0 = on the
+ *                   caller's tree.  Same image either way, bit for bit: the reference never prunes, so a leaf is tested iff the
+ *                   ray hits the leaf's own box (nested boxes) — any tree over the caller's leaf boxes tests the same leaves;
+ *                   ties on t are settled in the caller's visit order (one box test at the node of the caller's tree where
+ *                   the two leaves' paths part), rays with a zero direction component are traced on the caller's tree.  The
+ *                   internal tree (pt_bvh_build_sweep) is kept when probe rays visit >= 10 % fewer nodes in it, the caller's
+ *                   boxes nest, and the scene has 16+ primitives.  DESIGN.md §12.
+ *   "top_cache"     1 (default) scenes read from global memory keep the most-visited top nodes of the tree in LDS, 0 = all from memory
+ *   "lds_budget_kb" LDS per block for traversal stacks + that cache (0 = 26: 6 resident blocks per CU)
  *   "chunk"         work items a wave reserves per atomic, 64..256 (0 = automatic: 128 for big launches)
  *   "xcd_regions"   0 (default) 8 row bands with XCD affinity, 1 = a single work queue
  *   "item_order"    1 (default) a band is worked through row by row (all samples of a row first), 0 = sample by sample
@@ -235,7 +242,10 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)
  * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables, 3 global + top of the tree in LDS), "top_nodes",
- * "passes", "occupancy", "blocks_per_cu", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned". */
+ * "passes", "occupancy", "blocks_per_cu", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned",
+ * "fast_tree" (an internal tree exists), "fast_tree_on" (the next exact render uses it), "fast_tree_depth",
+ * "fast_tree_cost_permille" (probe-ray node visits, internal / caller's x 1000; 0 = none built), "stack_entries" (per lane),
+ * "redo_segments" (with "stats": segments of the last frame traced on the caller's tree), "debug_reruns" (same for pt_debug_intersect). */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
 int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
 

@@ -95,9 +95,9 @@ constexpr uint64_t kDefaultScratchBytes = 8ull << 30;   // per-sample scratch ca
 constexpr uint32_t kTopNodes = PT_TOP_NODES;              // scenes read from global memory: this many nodes are numbered breadth-first
                                                  // from the root, so that [0, k) is the top of the tree for every k (LDS cache)
 #ifndef PT_TOP_LDS_KB
-#define PT_TOP_LDS_KB 31
+#define PT_TOP_LDS_KB 26
 #endif
-constexpr uint32_t kTopLdsBudget = PT_TOP_LDS_KB * 1024;    // LDS per block that keeps 5 blocks per CU resident (160 KB / 5, minus slack)
+constexpr uint32_t kTopLdsBudget = PT_TOP_LDS_KB * 1024;    // LDS per block that keeps 6 blocks per CU resident (160 KB / 6)
 constexpr uint32_t kMaxLdsBudget = 160 * 1024;               // the breadth-first numbered prefix is sized for the largest budget an option may ask for
 constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band counters, one 128-B line each
 constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
@@ -155,7 +155,7 @@ struct pt_scene {
     int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
     int64_t opt_fast_tree = 1;       // exact traversal on the internal surface-area-cost tree with reference-order reruns (0 = on the caller's tree)
     int64_t opt_chunk = 0;           // work items a wave reserves per atomic (0 = automatic)
-    int64_t opt_lds_budget_kb = 0;   // scenes in global memory: LDS per block for traversal stacks + top-of-tree cache (0 = 31 KB: 5 blocks per CU)
+    int64_t opt_lds_budget_kb = 0;   // scenes in global memory: LDS per block for traversal stacks + top-of-tree cache (0 = 26 KB: 6 blocks per CU)
     int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
     int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
@@ -786,9 +786,11 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         S->cfg_fn = reinterpret_cast<const void*>(fn); S->cfg_lds = lp.total; S->cfg_occ = std::max(q, 1);
     }
     const int occ = S->cfg_occ;
-    // scenes read from global memory run best with at most 5 blocks per CU (more resident rays thrash L1/L2:
-    // bunny 10.9 ms at 5, 11.4 ms at 7; tools/gpu_occ_test.py); LDS-resident scenes take every block they can get
-    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (!lds_scene ? std::min(occ, 5) : occ);
+    // scenes read from global memory: 6 blocks per CU (what 80 VGPRs allow) with a 26 KB stack + top-of-tree budget each.
+    // With the internal tree's short stacks (its Strahler number, not its depth) the sixth block no longer costs cached nodes
+    // worth having: bunny +0.6 %, buddha stand-in -1.1 %, dragon stand-in -7.6 % against 5 blocks of 31 KB
+    // (profiles/r02_tune_round41_lds_budget.log, r02_tune_round42_blocks.log).  LDS-resident scenes take every block they can get.
+    int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (!lds_scene ? std::min(occ, 6) : occ);
     S->info_occupancy = occ;
     S->info_blocks_per_cu = bpc;
     S->info_lds_bytes = lp.total;
