@@ -221,7 +221,8 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel
  *   "v2_thresh" / "v2_inner" / "v2_minw"   scheduler variant of kernel 2; 0 = automatic (by scene residency).
  *                   v2_inner: < 0 vote burst of -n steps; 1..9 n inner steps + 1 leaf step per burst; >= 100 encodes
- *                   rounds*100 + inner*10 + leaf steps (162 = 6 inner + 2 leaf steps).  Only compiled-in variants are
+ *                   rounds*100 + inner*10 + leaf steps (162 = 6 inner + 2 leaf steps); 1000 + burst = the same burst with
+ *                   leaves set aside and tested together (internal tree only).  Only compiled-in variants are
  *                   accepted (PT_ERR_INVALID_ARG otherwise); every variant renders the same bits.
  *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
  *   "fast_tree"     1 (default) exact traversal on the library's INTERNAL tree where pt_scene_create kept one, 0 = on the

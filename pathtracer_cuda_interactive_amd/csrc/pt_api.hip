@@ -636,6 +636,7 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
+    PT_V2(32, 1004, 6)
 #undef PT_V2
     return nullptr;
 }
@@ -669,13 +670,17 @@ int scene_residency(const pt_scene* S, int which = 0) {
     return 1;
 }
 
-TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats) {
+TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats, bool internal_tree) {
     if (S->opt_kernel == 2) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
         const bool lds = res == 1 || res == 2;
         if (t == 0) t = lds ? 40 : 32;
         const bool tri = S->tri_only && S->opt_specialize;
-        if (i == 0) i = lds ? 162 : 4;              // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1
+        // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1, on the internal tree with leaves set aside (v2_inner
+        // 1000 + burst: bunny -2.2 %, dragon stand-in -3.4 %; LDS-resident scenes lose 9 % with it —
+        // profiles/r02_tune_round43_postponed_leaves.log)
+        if (i == 0) i = lds ? 162 : (internal_tree ? 1004 : 4);
+        if (i >= 1000 && !internal_tree) return nullptr;        // order-free leaf tests need the internal tree's tie handling
         if (w == 0) w = 6;
         const int spec = !tri ? 0 : (S->diffuse_only ? 2 : 1);
         return pick_kernel_v2(res, prune, stats, spec, t, i, w);
@@ -776,7 +781,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (nee && (S->opt_kernel != 2 || traversal != PT_TRAVERSAL_EXACT))
         return fail(PT_ERR_UNSUPPORTED, "PT_RENDER_NEE runs on the default kernel with exact traversal only");
     TraceFn fn = nee ? pick_kernel_nee(res, S->opt_stats != 0, (S->tri_only && S->diffuse_only && S->opt_specialize) ? 2 : 0)
-                     : pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0);
+                     : pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0, which == 1);
     if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
     if (S->cfg_fn != reinterpret_cast<const void*>(fn) || S->cfg_lds != lp.total) {
         if (lp.total > 64 * 1024)
@@ -801,7 +806,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         const size_t lanes = (size_t)S->num_cus * 8 * kBlock;
         if ((rc = S->redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
     }
-    select_tree(S, which, which == 1 && S->opt_fast_tree != 2);   // (fast_tree = 2: timing experiment without reruns — NOT exact)
+    select_tree(S, which, which == 1);
     float* accum = mode == 2 ? out_dev : S->accum.p;
     for (int pass = 0; pass < n_pass; pass++) {
         const int s0 = pass * (int)spp_pass;
@@ -1058,7 +1063,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
         const int w = which_tree(S, k == "vgprs_pruned" ? PT_TRAVERSAL_PRUNED : PT_TRAVERSAL_EXACT);
-        TraceFn fn = pick_kernel(S, scene_residency(S, w), k == "vgprs_pruned", S->opt_stats != 0);
+        TraceFn fn = pick_kernel(S, scene_residency(S, w), k == "vgprs_pruned", S->opt_stats != 0, w == 1);
         if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
         *value = fa.numRegs;

@@ -324,6 +324,12 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
     constexpr bool TRI_ONLY = SPEC >= 1, DIFFUSE_ONLY = SPEC >= 2;
     using STK = typename std::conditional<RES == 1 || RES == 2, int16_t, int32_t>::type;
     constexpr int32_t DONE = ptd::done_value<STK>();
+    // INNER >= 1000 (internal tree only — exact traversal there may test leaves in ANY order): a lane that reaches a leaf sets
+    // it aside (`pend`) and goes on with the next stack entry; the set-aside leaves are tested in the burst's leaf steps, when
+    // many lanes have one, instead of every lane stalling on its leaf until the burst gets there.
+    constexpr bool POSTPONE = INNER >= 1000;
+    constexpr int BURST = INNER >= 1000 ? INNER - 1000 : INNER;
+    int32_t pend = DONE;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     STK* stk = reinterpret_cast<STK*>(smem + lp.stack_off) + (size_t)wave * scn.stack_cap * 64 + lane;
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
     unsigned long long dg_iter = 0, dg_sched = 0, dg_sched_lanes = 0, dg_in = 0, dg_in_lanes = 0, dg_lf = 0, dg_lf_lanes = 0, dg_wait = 0;
 
     for (;;) {
-        const bool idle = tv.cur == DONE;
+        const bool idle = tv.cur == DONE && (!POSTPONE || pend == DONE);
         const unsigned long long idle_mask = __ballot(idle);
         if (STATS) dg_iter++;
         const bool work_left = !(feed.exhausted && feed.cur >= feed.end);        // wave-uniform
@@ -456,7 +462,48 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
             }
         }
         // ---- traversal burst
-        if (INNER < 0) {
+        if (POSTPONE) {
+            constexpr int REPS = BURST >= 100 ? BURST / 100 : 1;
+            constexpr int N_IN = BURST >= 100 ? (BURST / 10) % 10 : BURST;
+            constexpr int N_LF = BURST >= 100 ? BURST % 10 : 1;
+#pragma unroll
+            for (int r = 0; r < REPS; r++) {
+#pragma unroll
+                for (int k = 0; k < N_IN; k++) {
+                    if (STATS) {
+                        const int n_in = __popcll(__ballot(tv.cur >= 0));
+                        if (n_in) { dg_in++; dg_in_lanes += (unsigned)n_in; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE && pend == DONE)); }
+                    }
+                    if (tv.cur >= 0) {
+                        if (STATS) st.nodes++;
+                        ptd::inner_step<PRUNE, RES == 2, STK, (RES == 3 ? 1 : 0)>(sv, ray.org, tv, stk);
+                        if (tv.cur < 0 && tv.cur != DONE && pend == DONE) {       // a leaf: set it aside, take the next entry
+                            pend = tv.cur;
+                            tv.sp--;
+                            tv.cur = stk[tv.sp * 64];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < N_LF; k++) {
+                    if (STATS) {
+                        const int n_lf = __popcll(__ballot(pend != DONE));
+                        if (n_lf) { dg_lf++; dg_lf_lanes += (unsigned)n_lf; dg_wait += (unsigned)__popcll(__ballot(tv.cur == DONE && pend == DONE)); }
+                    }
+                    if (pend != DONE) {
+                        if (STATS) st.leaves++;
+                        ptd::leaf_test<TRI_ONLY>(sv, ray, tv, pend, fbk);
+                        pend = DONE;
+                        if (NEE && in_shadow && tv.best.prim >= 0) { tv.cur = DONE; tv.sp = 1; }      // occluded: done
+                        if (tv.cur < 0 && tv.cur != DONE) {                       // the lane was blocked on a second leaf
+                            pend = tv.cur;
+                            tv.sp--;
+                            tv.cur = stk[tv.sp * 64];
+                        }
+                    }
+                }
+            }
+        } else if (INNER < 0) {
             // "vote" schedule: each step runs the step kind (inner-node visit or leaf test) that more lanes wait for
 #pragma unroll
             for (int k = 0; k < -INNER; k++) {

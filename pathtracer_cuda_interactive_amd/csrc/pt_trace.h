@@ -222,10 +222,10 @@ __device__ __forceinline__ bool ref_visits_first(const SceneView& sv, const V3& 
 // One leaf visit (requires t.cur < 0 && t.cur != done_value<STK>()): primitive test, keep the hit if strictly closer, pop.
 // TRI_ONLY: the scene holds no sphere, the sphere branch is compiled out.
 // ANYHIT (kernels built with next-event estimation): a lane tracing a shadow ray (`shadow`) stops at the first hit.
-template <class STK, bool TRI_ONLY, bool ANYHIT = false>
-__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk, const bool shadow = false,
-                                          const bool ties = false) {
-    const int32_t prim = ~t.cur;
+// leaf_test: the primitive test alone, for leaf reference `ref` (= ~primitive); leaf_step: test of t.cur, then pop.
+template <bool TRI_ONLY>
+__device__ __forceinline__ void leaf_test(const SceneView& sv, const Ray& ray, Trav& t, const int32_t ref, const bool ties) {
+    const int32_t prim = ~ref;
     const DPrim* pr = sv.prims + prim;
     const float4 a = ld4(pr, 0);
     const float4 b = ld4(pr, 1);
@@ -285,6 +285,12 @@ __device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, T
             }
         }
     }
+}
+
+template <class STK, bool TRI_ONLY, bool ANYHIT = false>
+__device__ __forceinline__ void leaf_step(const SceneView& sv, const Ray& ray, Trav& t, STK* stk, const bool shadow = false,
+                                          const bool ties = false) {
+    leaf_test<TRI_ONLY>(sv, ray, t, t.cur, ties);
     if (ANYHIT && shadow && t.best.prim >= 0) t.sp = 1;      // occluded: drop the rest of the stack, the pop below ends the traversal
     t.sp--;                       // sentinel at the stack bottom: popping an empty stack yields kDone
     t.cur = stk[t.sp * 64];

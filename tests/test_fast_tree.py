@@ -250,3 +250,31 @@ def test_internal_tree_is_kept_only_where_it_touches_fewer_boxes(oracle):
         assert c.node_visits == cnt.inner_pops
     else:
         assert c.node_visits < cnt.inner_pops
+
+
+@pytest.mark.gpu
+def test_leaves_set_aside_is_an_internal_tree_schedule_only(oracle):
+    """Scenes in global memory on the internal tree run the burst that sets leaves aside (v2_inner 1004): leaf tests in an
+    order no tree prescribes.  Right on the internal tree (ties are settled by the caller's order whatever the test order),
+    refused on the caller's tree, where the visit order IS the tie rule."""
+    from pathtracer_cuda_interactive_amd import PT_ERR_INVALID_ARG, PtError
+    hs, d = load_scene("teapot")
+    p = hs.render_params(96, 72, 4, seed=8)
+    want, cnt = oracle.render(d, p)
+    ds = dev.DeviceScene(d)
+    try:
+        ds.set_option("stats", 1)
+        for inner in (0, 1004, 4):               # 0 = automatic = 1004 here
+            ds.set_option("v2_inner", inner)
+            img = ds.render(p)
+            assert_bit_equal(img, want, f"teapot v2_inner={inner}")
+            assert_work_counters(ds, ds.counters(), cnt, oracle, d, p, f"teapot v2_inner={inner}")
+        ds.set_option("fast_tree", 0)
+        ds.set_option("v2_inner", 1004)
+        with pytest.raises(PtError) as e:
+            ds.render(p)
+        assert e.value.status == PT_ERR_INVALID_ARG
+        ds.set_option("v2_inner", 0)
+        assert_bit_equal(ds.render(p), want, "teapot on the caller's tree")
+    finally:
+        ds.close()

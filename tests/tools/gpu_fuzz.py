@@ -7,6 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import oracle_binding as ob
 from conftest import random_scene
+from test_fast_tree import scene_with_ties
 from pathtracer_cuda_interactive_amd import PT_TRAVERSAL_PRUNED
 from pathtracer_cuda_interactive_amd import device as dev
 
@@ -16,10 +17,14 @@ t0 = time.time()
 by_res = {}
 flips = 0
 reruns = 0
+internal = 0
 for k in range(n):
     n_tris = int(rng.choice([0, 2, 3, 7, 30, 45, 60, 150, 190, 230, 400, 900, 2500, 6000]))
     n_sph = int(rng.integers(0, 6)) if n_tris else int(rng.integers(1, 6))
-    hs = random_scene(1000 + k, n_tris=n_tris, n_spheres=n_sph, emissive=bool(rng.integers(0, 2)))
+    if k % 3 == 2:       # clouds of small triangles with doubled geometry: the kind of scene that keeps the internal tree, full of ties
+        hs = scene_with_ties(1000 + k, n_tris=max(n_tris, 20))
+    else:
+        hs = random_scene(1000 + k, n_tris=n_tris, n_spheres=n_sph, emissive=bool(rng.integers(0, 2)))
     d = hs.finalize(int(rng.integers(0, 2)))
     w, h, spp = [(48, 36, 3), (33, 17, 5), (64, 8, 2), (20, 50, 4)][k % 4]
     p = hs.render_params(w, h, spp, seed=int(rng.integers(0, 1 << 30)))
@@ -31,6 +36,7 @@ for k in range(n):
     by_res[res] = by_res.get(res, 0) + 1
     img = ds.render(p)                       # default: scenes in global memory run on the internal tree with reference-order reruns
     reruns += ds.info("redo_segments")
+    internal += ds.info("fast_tree_on")
     ok = bool((img.view(np.uint32) == want.view(np.uint32)).all())
     ds.set_option("fast_tree", 0)            # the caller's tree: counters must equal the oracle's
     img0 = ds.render(p)
@@ -47,4 +53,4 @@ for k in range(n):
     if k % 50 == 49:
         print(f"{k + 1} scenes ok, {time.time() - t0:.1f} s", flush=True)
 print(f"fuzz ok: {n} scenes, residencies {dict(sorted(by_res.items()))}, pruned traversal flipped {flips} pixels in total, "
-      f"{reruns} segments rerun in reference order on the internal-tree path")
+      f"{internal} scenes on the internal tree, {reruns} of their segments traced on the caller's tree (zero direction component)")
