@@ -636,7 +636,7 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
-    PT_V2(32, 1004, 6)
+    PT_V2(32, 1004, 6) PT_V2(40, 142, 6) PT_V2(40, 152, 6) PT_V2(40, 132, 6) PT_V2(40, 221, 6)
 #undef PT_V2
     return nullptr;
 }

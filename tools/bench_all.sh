@@ -8,6 +8,11 @@ for S in cbox bunny scene1 buddha_standin dragon_standin; do
   python3 -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_bench_$S.json')); print('$S', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['physical'], d.get('cpu_baseline',{}).get('value'))"
 done
 python3 bench.py --scene bunny --traversal pruned --no-cpu-baseline > gpurun_out/${TAG}_bench_bunny_pruned.json 2>/dev/null
+# the same configs on the caller's (reference median-split) tree instead of the library's internal one: same images, more node visits
+for S in cbox bunny buddha_standin dragon_standin; do
+  python3 bench.py --scene $S --tree caller --no-cpu-baseline > gpurun_out/${TAG}_bench_${S}_callers_tree.json 2>/dev/null
+  python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_${S}_callers_tree.json')); print('$S caller tree', d['ms_per_step'], d['value'])"
+done
 for S in scene1 cbox bunny; do python3 bench.py --scene $S --progressive 2 --steps 200 --warmup 20; done > gpurun_out/${TAG}_bench_progressive.jsonl 2>/dev/null
 cat gpurun_out/${TAG}_bench_progressive.jsonl | python3 -c "
 import sys,json
