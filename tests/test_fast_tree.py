@@ -278,3 +278,34 @@ def test_leaves_set_aside_is_an_internal_tree_schedule_only(oracle):
         assert_bit_equal(ds.render(p), want, "teapot on the caller's tree")
     finally:
         ds.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h,spp", [("cbox", 640, 480, 64), ("bunny", 640, 480, 64), ("buddha_standin", 1280, 960, 8)])
+def test_full_size_frames_are_the_same_on_both_trees(name, w, h, spp):
+    """BASELINE-size frames (too big for the oracle): internal tree == caller's tree, bit for bit, every pixel.  Events as rare
+    as 1 ray in 1e7 — a zero direction component, a three-way tie — only show up at this size."""
+    import os
+
+    from conftest import SCENES
+    from pathtracer_cuda_interactive_amd import HostScene, standins
+    if name in standins.BUILDERS:
+        hs = standins.BUILDERS[name](SCENES)
+        d = hs.finalize(0)
+    else:
+        hs, d = load_scene(name)
+    p = hs.render_params(w, h, spp)
+    ds = dev.DeviceScene(d)
+    try:
+        assert ds.info("fast_tree_on") == 1
+        ds.set_option("stats", 1)
+        a = ds.render(p)
+        reruns = ds.info("redo_segments")
+        ds.set_option("stats", 0)
+        ds.set_option("fast_tree", 0)
+        b = ds.render(p)
+    finally:
+        ds.close()
+    assert_bit_equal(a, b, f"{name} {w}x{h}x{spp}: internal tree vs caller's tree")
+    if name != "bunny":
+        assert reruns > 0            # the rerun path did run in this frame
