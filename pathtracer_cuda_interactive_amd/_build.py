@@ -28,6 +28,7 @@ HIP_FLAGS = [
     # SLP vectorisation turns the scalar fp32 vector math into v_pk_add/mul_f32 plus ~20 v_mov shuffles per leaf test;
     # packed fp32 issues at half rate on gfx950, so the packing only adds instructions: cbox 4.21 -> 3.78 ms without it
     "-fno-slp-vectorize",
+    "-pthread",                               # pt_tree_sweep.h builds big trees on a few host threads
 ]
 
 

@@ -633,7 +633,8 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 // T32 / I4 / W6 (bunny 10.7 ms; every other burst shape within 1 %).  I8 and unbounded descent are slower, T56 starves the
 // scheduler phase, W6 (<= 80 VGPRs -> 6 waves/SIMD) beats the unconstrained 82-VGPR build by 3-5 %, W8 (64 VGPRs, spills)
 // is 5-8 % slower.  Re-checked on the internal tree (fewer inner visits per leaf test): 6 + 2 still wins on LDS-resident scenes
-// (cbox: 5+2 +2.4 %, 4+2 +4.6 %, 3+2 +5.4 %, two rounds of 2+1 +13 %; profiles/r02_tune_round44_lds_bursts_rejected.log).
+// (cbox: 5+2 +2.4 %, 4+2 +4.6 %, 3+2 +5.4 %, two rounds of 2+1 +13 %; thresholds 24 / 32 / 48 / 56: +1.7 / 0.0 / +1.2 / +7.5 %; profiles/r02_tune_round44_lds_bursts_rejected.log,
+// r02_tune_round46_thresh_rejected.log).
 TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)

@@ -13,7 +13,8 @@ from pathtracer_cuda_interactive_amd.ctypes_defs import PtBvhNode, PtSceneDesc
 
 
 @pytest.mark.parametrize("name,w,h,spp,gain", [("cbox", 64, 48, 8, 0.75), ("scene4", 64, 48, 8, 0.9), ("teapot", 64, 48, 2, 0.35),
-                                               ("tetrahedron", 33, 17, 4, 1.01), ("scene1", 40, 30, 4, 1.01)])
+                                               ("tetrahedron", 33, 17, 4, 1.01), ("scene1", 40, 30, 4, 1.01),
+                                               ("bunny", 48, 36, 2, 0.45)])       # 288 k primitives: the threaded build
 def test_sweep_tree_is_a_valid_cover_and_cheaper_to_traverse(oracle, name, w, h, spp, gain):
     hs, d = load_scene(name)
     d2, info = dev.build_bvh_sweep(d)
