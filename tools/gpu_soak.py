@@ -30,6 +30,7 @@ for it in range(n):
     ds.set_option("item_order", (it // 23) % 2)
     ds.set_option("chunk", [0, 64, 128, 256][(it // 29) % 4])
     ds.set_option("lds_budget_kb", [0, 24, 39][(it // 31) % 3])
+    ds.set_option("fast_tree", 0 if (it // 41) % 3 == 2 else 1)      # internal or caller's tree: the frame must not care
     nee = kernel == 2 and (it // 37) % 2 == 1
     p = hs.render_params(w, h, spp)
     p.flags = PT_RENDER_NEE if nee else 0
