@@ -314,6 +314,18 @@ def main():
     else:
         total_segs, total_paths, kern = t[1].item(), t[2].item(), t[3].item()
 
+    # Work the kernel really did per segment (one extra, untimed frame with the counting build of the kernel, rank 0's rows):
+    # the algorithmic figures below price the REFERENCE's traversal of the REFERENCE's tree; this is what was traversed.
+    work = None
+    if not stub:
+        R.scene.set_option("stats", 1)
+        R.render(params, rank, world)
+        cw = R.scene.counters()
+        R.scene.set_option("stats", 0)
+        if cw.segments:
+            work = {"inner_visits_per_segment": round(cw.node_visits / cw.segments, 3),
+                    "leaf_tests_per_segment": round(cw.leaf_tests / cw.segments, 3),
+                    "segments_traced_on_the_callers_tree": int(R.scene.info("redo_segments"))}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_segs / elapsed / 1e6
@@ -360,6 +372,7 @@ def main():
                        # same closest hits (ties in the caller's visit order), fewer inner visits; "caller" = --tree caller
                        "tree": ("stub" if stub else "internal" if (args.traversal == "exact" and R.scene.info("fast_tree_on")) else "caller"),
                        "stack_entries": 0 if stub else int(R.scene.info("stack_entries")),
+                       "work": work,
                        "frame_mean": round(float(frame.mean().item()), 6)},
             # SURVEY §8d's fields, exactly as defined there: ALGORITHMIC bytes of the reference layout per second against the HBM
             # peak (can exceed 1: those bytes are served by LDS / L1 / L2, not by HBM).  `physical` names the bound that really

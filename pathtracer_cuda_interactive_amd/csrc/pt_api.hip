@@ -429,9 +429,14 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         if (finite) {
             std::vector<pt_bvh_node> fnodes;
             int32_t froot = 0, fdepth = 0;
-            pts::build_sweep_tree(leaf_boxes.data(), N, fnodes, &froot, &fdepth);
+            bool built = true;
+            try {
+                pts::build_sweep_tree(leaf_boxes.data(), N, fnodes, &froot, &fdepth);
+            } catch (const std::exception&) {        // out of host memory: the caller's tree serves alone
+                built = false;
+            }
             bool fnested = true;
-            have_fast = convert_tree(fnodes.data(), d->num_nodes, froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
+            have_fast = built && convert_tree(fnodes.data(), d->num_nodes, froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
         }
     }
     const TreeHost* hosts[2] = {&ref, have_fast ? &fast : nullptr};
@@ -1132,7 +1137,11 @@ int pt_bvh_build_sweep(const pt_scene_desc* d, pt_bvh_node* out_nodes, int32_t* 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<pt_bvh_node> nodes;
     int32_t root = 0, depth = 0;
-    pts::build_sweep_tree(boxes.data(), N, nodes, &root, &depth);
+    try {
+        pts::build_sweep_tree(boxes.data(), N, nodes, &root, &depth);
+    } catch (const std::exception& e) {
+        return fail(PT_ERR_DEVICE, std::string("pt_bvh_build_sweep: ") + e.what());
+    }
     std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(pt_bvh_node));
     *out_root = root;
     if (out_depth) *out_depth = depth;

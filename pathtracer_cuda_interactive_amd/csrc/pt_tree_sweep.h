@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -45,6 +46,24 @@ inline double sbox_area(const SBox& b) {
     return 2.0 * (x * y + y * z + z * x);
 }
 
+// Runs the jobs 1 .. count-1 on threads of their own and job 0 on the caller's; a thread that cannot be started (process or
+// thread limits of the host) simply means its job runs on the caller's thread as well.  Jobs must be independent.
+template <class F>
+inline void run_side_by_side(int count, F&& job) {
+    std::vector<std::thread> side;
+    std::vector<int> inline_jobs;
+    for (int k = 1; k < count; k++) {
+        try {
+            side.emplace_back([&job, k]() { job(k); });
+        } catch (const std::system_error&) {
+            inline_jobs.push_back(k);
+        }
+    }
+    job(0);
+    for (int k : inline_jobs) job(k);
+    for (std::thread& t : side) t.join();
+}
+
 // leaf_boxes: n x {lo.xyz, hi.xyz}, all finite.  out: the reference's node pool layout (bvh.cuh:7-15), 2n-1 nodes in
 // pre-order (node, left subtree, right subtree), root = 0.  Inner boxes are exact unions (min / max do not round).
 inline void build_sweep_tree(const float* leaf_boxes, int n, std::vector<pt_bvh_node>& out, int32_t* out_root, int32_t* out_depth) {
@@ -69,10 +88,7 @@ inline void build_sweep_tree(const float* leaf_boxes, int n, std::vector<pt_bvh_
         }
     };
     if (n >= 65536) {
-        std::thread ty(sort_axis, 1), tz(sort_axis, 2);
-        sort_axis(0);
-        ty.join();
-        tz.join();
+        run_side_by_side(3, sort_axis);
     } else {
         for (int a = 0; a < 3; a++) sort_axis(a);
     }
@@ -136,10 +152,7 @@ inline void build_sweep_tree(const float* leaf_boxes, int n, std::vector<pt_bvh_
                 }
             };
             if (wide) {
-                std::thread ty(sweep, 1), tz(sweep, 2);
-                sweep(0);
-                ty.join();
-                tz.join();
+                run_side_by_side(3, sweep);
             } else {
                 for (int a = 0; a < 3; a++) sweep(a);
             }
@@ -167,9 +180,7 @@ inline void build_sweep_tree(const float* leaf_boxes, int n, std::vector<pt_bvh_
         };
         const int oa = (best_axis + 1) % 3, ob = (best_axis + 2) % 3;
         if (wide) {
-            std::thread other(partition, ob);
-            partition(oa);
-            other.join();
+            run_side_by_side(2, [&](int k) { partition(k == 0 ? oa : ob); });
         } else {
             partition(oa);
             partition(ob);
@@ -224,13 +235,10 @@ inline void build_sweep_tree(const float* leaf_boxes, int n, std::vector<pt_bvh_
         std::sort(pending.begin(), pending.end(), [](const Task& x, const Task& y) { return (x.e - x.b) > (y.e - y.b) || ((x.e - x.b) == (y.e - y.b) && x.b < y.b); });
         std::atomic<size_t> next{0};
         std::vector<int> deepest(workers, 1);
-        std::vector<std::thread> pool;
-        for (unsigned w = 0; w < workers; w++)
-            pool.emplace_back([&, w]() {
-                for (size_t k = next.fetch_add(1); k < pending.size(); k = next.fetch_add(1))
-                    deepest[w] = std::max(deepest[w], run_subtree(pending[k]));
-            });
-        for (std::thread& th : pool) th.join();
+        run_side_by_side((int)workers, [&](int w) {
+            for (size_t k = next.fetch_add(1); k < pending.size(); k = next.fetch_add(1))
+                deepest[w] = std::max(deepest[w], run_subtree(pending[k]));
+        });
         for (int dd : deepest) depth = std::max(depth, dd);
     }
     *out_root = 0;
