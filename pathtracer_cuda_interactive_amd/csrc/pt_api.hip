@@ -153,7 +153,7 @@ struct pt_scene {
     int64_t opt_specialize = 1;      // compile-time specialisation on scene content (no spheres -> sphere code removed)
     int64_t opt_octants = 1;         // use the 8 ray-octant node tables when the scene is small enough
     int64_t opt_top_cache = 1;       // scenes in global memory: keep the top of the tree in LDS
-    int64_t opt_fast_tree = 1;       // exact traversal on the internal surface-area-cost tree with reference-order reruns (0 = on the caller's tree)
+    int64_t opt_fast_tree = 1;       // exact traversal on the library's internal tree where one was kept (0 = on the caller's tree)
     int64_t opt_chunk = 0;           // work items a wave reserves per atomic (0 = automatic)
     int64_t opt_lds_budget_kb = 0;   // scenes in global memory: LDS per block for traversal stacks + top-of-tree cache (0 = 26 KB: 6 blocks per CU)
     int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
@@ -178,8 +178,8 @@ struct pt_scene {
 
 namespace {
 
-// Points the kernel argument block at one of the two layouts; fallback: exact traversal on the internal tree reruns the rays
-// whose result depends on the visit order on tree[0].
+// Points the kernel argument block at one of the two trees; fallback: exact traversal on the internal tree — ties settled in the
+// caller's visit order, rays with a zero direction component traced on tree[0].
 void select_tree(pt_scene* S, int which, bool fallback = false) {
     const pt_scene::Tree& T = S->tree[which];
     SceneDev& dv = S->dev;
@@ -775,9 +775,10 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
 
     const int traversal = p->traversal == PT_TRAVERSAL_DEFAULT ? PT_TRAVERSAL_EXACT : p->traversal;
     if (traversal != PT_TRAVERSAL_EXACT && traversal != PT_TRAVERSAL_PRUNED) return fail(PT_ERR_INVALID_ARG, "unknown traversal mode");
-    // Exact traversal runs on the internal tree and reruns, in reference order on the caller's tree, the rays whose closest
-    // hit depends on the visit order: two valid hits with equal t (the first one VISITED wins, scene.h:270) and rays with a
-    // zero direction component (1/d infinite: the monotonicity argument of validate_and_build does not cover 0 * inf).
+    // Exact traversal runs on the internal tree where scene creation kept one.  What depends on the visit order is handled the
+    // reference's way: two valid hits with equal t (the first one VISITED wins, scene.h:270) are ordered by one box test in
+    // the caller's tree (pt_trace.h: ref_visits_first); rays with a zero direction component (1/d infinite: the monotonicity
+    // argument of validate_and_build does not cover 0 * inf) are traced on the caller's tree in reference order.
     const int which = which_tree(S, traversal);
     const int res = scene_residency(S, which);
     const bool lds_scene = res == 1 || res == 2;

@@ -195,7 +195,7 @@ __device__ __forceinline__ ptd::SceneView make_scene_view(const SceneDev& scn, c
 // 12 k of them at the end of a 6144-wave launch were ~60 us of every frame), so the sums are spread over kCounterSlots
 // slots of one 128-B line each, picked by workgroup id; the host adds the slots up (pt_get_counters).
 // Slot layout (uint64): [0] paths [1] segments [2] node visits [3] leaf tests [4..11] schedule diagnostics
-// [12] segments rerun in reference order (exact traversal on the internal tree).
+// [12] segments traced on the caller's tree in reference order (exact traversal on the internal tree: zero direction component).
 // After the slots: launch timeline [kTimelineBase + 0..7] and two 128-bin histograms (STATS builds only).
 constexpr int kCounterSlots = 64;
 constexpr int kSlotStride = 16;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock, (kBlock > 256 ? 1 : MINW)) void trace_kerne
     uint32_t n_paths = 0, n_segs = 0;
     ptd::TravStats st;
     st.nodes = 0; st.leaves = 0;
-    // exact traversal on the internal tree (scn.fallback): reruns in reference order use the caller's tree and a
+    // exact traversal on the internal tree (scn.fallback): rays with a zero direction component use the caller's tree and a
     // global-memory stack column of their own (the LDS columns belong to the lanes that are still traversing)
     const bool fbk = scn.fallback != 0;                       // wave-uniform
     ptd::SceneView sv_ref = sv;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     r.tfar = rays[8 * k + 7];
     ptd::TravStats st;
     ptd::Hit h;
-    if (!PRUNE && scn.fallback) {                         // internal tree, reference-order rerun where the order matters
+    if (!PRUNE && scn.fallback) {                         // internal tree; the caller's for rays with a zero direction component
         ptd::SceneView sv_ref = sv;
         sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref; sv_ref.fixed_order = 0;
         bool rerun;

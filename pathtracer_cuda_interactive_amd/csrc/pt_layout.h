@@ -73,8 +73,9 @@ struct SceneDev {
     int32_t root_ref;
     int32_t stack_cap;              // entries per lane needed (= BVH depth)
     float bg[3];
-    // exact traversal on the internal tree: rays whose result depends on the visit order are rerun on the caller's tree
-    int32_t fallback;               // 1 = `nodes` is the internal tree; ties on t / infinite 1/d trigger a reference-order rerun
+    // exact traversal on the internal tree: ties on t are settled in the caller's visit order (ref_path / ref_anc below), rays
+    // with a zero direction component are traced on the caller's tree instead
+    int32_t fallback;               // 1 = `nodes` is the internal tree: both mechanisms are on
     const DNode* ref_nodes;         // the caller's tree (plain layout, global memory)
     int32_t ref_root_ref;
     int32_t redo_cap;               // stack entries per lane of a rerun

@@ -72,8 +72,8 @@ struct Trav {
     int32_t cur;       // node reference being visited; kDone = traversal finished
     int32_t sp;        // entries on this lane's LDS stack column
     uint32_t node_off; // byte offset of the node table this ray reads (octant copy), 0 when there is one table
-    bool redo;         // traversal of the internal tree: the closest hit depends on the visit order (two hits tied on t, or
-                       // 1/d infinite) — this ray is traced again on the caller's tree in the reference's order
+    bool redo;         // traversal of the internal tree: 1/d is infinite on an axis (0 * inf in the slab test lies outside the
+                       // argument that lets that tree stand in) — this ray is traced on the caller's tree in the reference's order
 };
 
 // The traversal stack lives in LDS, one column per lane (entry k at stk[k*64]).  Its element type STK is int32_t, or
@@ -316,9 +316,9 @@ __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, in
     return t.best;
 }
 
-// The same closest hit — ties and all — traversed on ANOTHER tree over the same leaf boxes (`sv`), with the caller's tree
-// (`sv_ref`) kept for the rays whose answer depends on the visit order: two candidates at equal t, or a direction with a
-// zero component (pt_api.hip: validate_and_build has the argument).  The trace kernel inlines the same three steps into its
+// The same closest hit — ties and all — traversed on ANOTHER tree over the same leaf boxes (`sv`): ties on t are settled in
+// the caller's visit order inside leaf_step (ref_visits_first), and a ray with a zero direction component is traced on the
+// caller's tree (`sv_ref`) instead (pt_api.hip: validate_and_build has the argument).  The trace kernel inlines the same three steps into its
 // scheduler; this run-to-completion form serves pt_debug_intersect.  `rerun` reports that the reference order was needed.
 __device__ __forceinline__ Hit intersect_any_tree(const SceneView& sv, const SceneView& sv_ref, const Ray& ray, int32_t* stk, bool& rerun) {
     Trav t;
