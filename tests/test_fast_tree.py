@@ -43,6 +43,7 @@ def scene_with_ties(seed, n_tris=3000):
     I = np.arange(900, dtype=np.int32).reshape(-1, 3)
     hs.add_mesh(P, I, red)
     hs.add_mesh(P.copy(), I.copy(), blue)                                   # the same 300 triangles again
+    hs.add_mesh(P[:450].copy(), I[:150].copy(), grey)                       # ... and half of them a third time: three-way ties
     m = GRID + 1
     g = np.linspace(-1.0, 1.0, m, dtype=np.float32)
     X, Y = np.meshgrid(g, g, indexing="xy")
