@@ -326,6 +326,13 @@ def main():
             work = {"inner_visits_per_segment": round(cw.node_visits / cw.segments, 3),
                     "leaf_tests_per_segment": round(cw.leaf_tests / cw.segments, 3),
                     "segments_traced_on_the_callers_tree": int(R.scene.info("redo_segments"))}
+            if args.traversal == "exact" and R.scene.info("fast_tree_on"):
+                # the same frame on the caller's tree: the visit count the algorithmic bytes are priced on
+                R.scene.set_option("fast_tree", 0); R.scene.set_option("stats", 1)
+                R.render(params, rank, world)
+                cr = R.scene.counters()
+                R.scene.set_option("stats", 0); R.scene.set_option("fast_tree", 1)
+                work["callers_tree_inner_visits_per_segment"] = round(cr.node_visits / max(cr.segments, 1), 3)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_segs / elapsed / 1e6
@@ -381,6 +388,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "physical": physical,
                          "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": passes, "pmc": pmc,
                          "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
+                         # "work avoided is not bandwidth achieved" (SURVEY §8d): the same figure with the inner visits this run
+                         # really made (60 B each in the reference layout) instead of the caller's tree's
+                         "work_done": (None if not (work and "callers_tree_inner_visits_per_segment" in work) else (lambda b: {
+                             "bytes_per_segment": round(b, 1), "achieved": round(b * seg_launch / (k_ms * 1e-3) / 1e9, 1),
+                             "frac": round(b * seg_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})(
+                             wl["bytes_per_segment"] - 60.0 * (work["callers_tree_inner_visits_per_segment"] - work["inner_visits_per_segment"]))),
                          "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
                                   "the physical bound is VALU lane throughput, see `physical` and DESIGN.md §7" % R.scene.info("scene_bytes")) if lds_scene else
                                  "working set (%.1f MB) is served by L2/Infinity Cache: the physical bound is the L2-miss path, see `physical` and DESIGN.md §7" % (R.scene.info("scene_bytes") / 1e6)},
