@@ -326,7 +326,7 @@ def main():
             work = {"inner_visits_per_segment": round(cw.node_visits / cw.segments, 3),
                     "leaf_tests_per_segment": round(cw.leaf_tests / cw.segments, 3),
                     "segments_traced_on_the_callers_tree": int(R.scene.info("redo_segments"))}
-            if args.traversal == "exact" and R.scene.info("fast_tree_on"):
+            if R.scene.info("fast_tree_on"):
                 # the same frame on the caller's tree: the visit count the algorithmic bytes are priced on
                 R.scene.set_option("fast_tree", 0); R.scene.set_option("stats", 1)
                 R.render(params, rank, world)
@@ -377,7 +377,7 @@ def main():
                        "vgprs": int(R.scene.info("vgprs_pruned" if args.traversal == "pruned" else "vgprs")),
                        # exact traversal runs on the library's internal tree where scene creation kept one: same leaves tested,
                        # same closest hits (ties in the caller's visit order), fewer inner visits; "caller" = --tree caller
-                       "tree": ("stub" if stub else "internal" if (args.traversal == "exact" and R.scene.info("fast_tree_on")) else "caller"),
+                       "tree": ("stub" if stub else "internal" if R.scene.info("fast_tree_on") else "caller"),
                        "stack_entries": 0 if stub else int(R.scene.info("stack_entries")),
                        "work": work,
                        "frame_mean": round(float(frame.mean().item()), 6)},

@@ -225,8 +225,8 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  *                   leaves set aside and tested together (internal tree only).  Only compiled-in variants are
  *                   accepted (PT_ERR_INVALID_ARG otherwise); every variant renders the same bits.
  *   "octants"       1 (default) keep 8 ray-octant node tables in LDS for very small scenes, 0 = one table
- *   "fast_tree"     1 (default) exact traversal on the library's INTERNAL tree where pt_scene_create kept one, 0 = on the
- *                   caller's tree.  Same image either way, bit for bit: the reference never prunes, so a leaf is tested iff the
+ *   "fast_tree"     1 (default) traversal (exact and pruned) on the library's INTERNAL tree where pt_scene_create kept one,
+ *                   0 = on the caller's tree.  Same image either way, bit for bit: the reference never prunes, so a leaf is tested iff the
  *                   ray hits the leaf's own box (nested boxes) — any tree over the caller's leaf boxes tests the same leaves;
  *                   ties on t are settled in the caller's visit order (one box test at the node of the caller's tree where
  *                   the two leaves' paths part), rays with a zero direction component are traced on the caller's tree.  The
