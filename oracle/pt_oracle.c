@@ -228,6 +228,14 @@ int pt_oracle_intersect(const pt_scene_desc* sc, const float* rays, int n, int m
     return intersect_rays_det(sc, rays, n, out_tuv, out_prim);
 }
 
+int pt_oracle_intersect_work(const pt_scene_desc* sc, const float* rays, int n, int math_mode, uint32_t* out_inner,
+                             uint32_t* out_leaf, uint64_t* out_leaf_set) {
+    if (!sc || !rays || !out_inner || !out_leaf || !out_leaf_set || n < 0) return PT_ERR_INVALID_ARG;
+    if (sc->num_nodes <= 0 || sc->root < 0 || sc->root >= sc->num_nodes) return PT_ERR_BAD_SCENE;
+    if (math_mode == PT_ORACLE_MATH_LIBM) return intersect_work_rays_libm(sc, rays, n, out_inner, out_leaf, out_leaf_set);
+    return intersect_work_rays_det(sc, rays, n, out_inner, out_leaf, out_leaf_set);
+}
+
 int pt_oracle_math(int op, int math_mode, const float* x, const float* y, float* out0, float* out1, int n) {
     for (int i = 0; i < n; i++) {
         if (op == 0) {

@@ -75,6 +75,11 @@ int pt_oracle_trace_pixels(const pt_scene_desc* scene, const pt_render_params* p
 int pt_oracle_intersect(const pt_scene_desc* scene, const float* rays, int n, int math_mode,
                         float* out_tuv, int32_t* out_prim);
 
+/* Work of intersect() per ray, primitive tests left out: inner pops, leaves reached, and an order-independent hash of the
+ * ids of the primitives whose leaves were reached (the reference never prunes, so this set does not depend on hits). */
+int pt_oracle_intersect_work(const pt_scene_desc* scene, const float* rays, int n, int math_mode, uint32_t* out_inner,
+                             uint32_t* out_leaf, uint64_t* out_leaf_set);
+
 /* math KATs: op 0 sincos(x)->(out0=sin,out1=cos); op 1 powf(x,y)->out0; math_mode as above */
 int pt_oracle_math(int op, int math_mode, const float* x, const float* y, float* out0, float* out1, int n);
 /* n_draws uint32 + float outputs of init_pcg32(stream, seed); also returns state/inc after init */

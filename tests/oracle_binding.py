@@ -115,6 +115,19 @@ def intersect(desc, rays, math_mode=MATH_DET):
     return tuv, prim
 
 
+def intersect_work(desc, rays, math_mode=MATH_DET):
+    """Per ray: (inner pops, leaves reached, order-independent hash of the primitive ids of those leaves)."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+    n = rays.shape[0]
+    inner = np.zeros(n, dtype=np.uint32)
+    leaf = np.zeros(n, dtype=np.uint32)
+    leaf_set = np.zeros(n, dtype=np.uint64)
+    lib().pt_oracle_intersect_work.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(lib().pt_oracle_intersect_work(C.byref(desc), _fp(rays), n, math_mode, inner.ctypes.data, leaf.ctypes.data,
+                                        leaf_set.ctypes.data), "oracle intersect_work")
+    return inner, leaf, leaf_set
+
+
 def sincos(x, math_mode=MATH_DET):
     x = np.ascontiguousarray(x, dtype=np.float32)
     s = np.zeros_like(x)

@@ -89,3 +89,60 @@ def test_one_and_two_primitives():
         d = hs.finalize(0)
         _, info = dev.build_bvh_sweep(d)
         assert check_tree(info["nodes"], info["root"], n, host_leaf_boxes(hs)) == info["depth"] == n
+
+
+def _rays_through(hs, rng, n):
+    """Rays that start anywhere around the scene and leave in any direction — no zero direction component."""
+    na = hs.nodes_array()
+    lo, hi = na["bmin"].min(axis=0), na["bmax"].max(axis=0)
+    ext = np.maximum(hi - lo, 1e-3)
+    o = (lo - 0.5 * ext + rng.random((n, 3)) * 2.0 * ext).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[d == 0] = np.float32(1e-3)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7] = o, d, 1e-4, np.inf
+    return rays
+
+
+@pytest.mark.parametrize("name,n_rays", [("cbox", 200000), ("scene4", 200000), ("teapot", 100000), ("bunny", 40000)])
+def test_any_tree_over_the_same_leaf_boxes_reaches_the_same_leaves(oracle, name, n_rays):
+    """The statement the internal tree stands on, checked ray by ray on the CPU: the reference's traversal (it never prunes)
+    reaches a leaf iff the ray hits the leaf's own box, so the caller's tree, the sweep tree and a deliberately bad tree — a
+    chain that peels one primitive off per level — all reach the SAME SET of leaves for every ray with finite 1/d.  Rays
+    with a zero direction component are outside the statement (when such a ray starts exactly on a box plane of that axis —
+    a bounce off an axis-aligned wall does — the slab test multiplies 0 by inf); the device traces those on the caller's tree."""
+    hs, d = load_scene(name)
+    rng = np.random.default_rng(11)
+    rays = _rays_through(hs, rng, n_rays)
+    inner0, leaf0, set0 = oracle.intersect_work(d, rays)
+    d_sweep, _ = dev.build_bvh_sweep(d)
+    inner1, leaf1, set1 = oracle.intersect_work(d_sweep, rays)
+    assert np.array_equal(leaf0, leaf1) and np.array_equal(set0, set1)
+    assert inner1.sum() < inner0.sum()
+    assert leaf0.max() > 0 and (leaf0 > 0).mean() > 0.05                     # the rays do reach leaves
+    if d.num_shapes <= 64:
+        # the worst tree there is: primitive k against everything after it (depth N), boxes = exact unions
+        lo, hi = host_leaf_boxes(hs)
+        n = d.num_shapes
+        nodes = np.zeros(2 * n - 1, dtype=dev.NODE_DTYPE)
+        suffix_lo = np.minimum.accumulate(lo[::-1], axis=0)[::-1]
+        suffix_hi = np.maximum.accumulate(hi[::-1], axis=0)[::-1]
+        for k in range(n):                      # leaves 0..n-1
+            nodes[k] = (lo[k], hi[k], -1, -1, k)
+        for k in range(n - 1):                  # inner node n+k covers primitives k..n-1
+            right = n - 1 if k == n - 2 else n + k + 1
+            nodes[n + k] = (suffix_lo[k], suffix_hi[k], k, right, -1)
+        d_chain = _desc_with_nodes(d, nodes, n)
+        inner2, leaf2, set2 = oracle.intersect_work(d_chain, rays)
+        assert np.array_equal(leaf0, leaf2) and np.array_equal(set0, set2)
+
+
+def _desc_with_nodes(desc, nodes, root):
+    d2 = PtSceneDesc()
+    C.memmove(C.byref(d2), C.byref(desc), C.sizeof(PtSceneDesc))
+    d2.nodes = nodes.ctypes.data_as(C.POINTER(PtBvhNode))
+    d2.num_nodes = len(nodes)
+    d2.root = root
+    d2._keep = (nodes, desc)
+    return d2
