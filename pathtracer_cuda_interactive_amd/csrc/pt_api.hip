@@ -557,10 +557,17 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             todo.push_back({nd.right, w.level + 1, w.turns | (1ull << w.level)});
             todo.push_back({nd.left, w.level + 1, w.turns});
         }
-        if ((rc = S->ref_path.ensure(path.size())) || (rc = S->ref_anc.ensure(anc.size()))) return rc;
-        HIP_TRY(hipMemcpy(S->ref_path.p, path.data(), path.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(S->ref_anc.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        S->ref_levels = levels;
+        if (S->ref_path.ensure(path.size()) || S->ref_anc.ensure(anc.size())) {
+            // no room for the tables (num_shapes x depth words): the scene simply keeps to the caller's tree
+            (void)hipGetLastError();
+            S->have_fast = false;
+            S->ref_path.release(); S->ref_anc.release();
+            S->tree[1].nodes.release(); S->tree[1].nodes_oct.release(); S->tree[1].have_oct = false;
+        } else {
+            HIP_TRY(hipMemcpy(S->ref_path.p, path.data(), path.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(S->ref_anc.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            S->ref_levels = levels;
+        }
     }
     select_tree(S, 0);
     S->scene_bytes = (uint32_t)std::min<size_t>(
