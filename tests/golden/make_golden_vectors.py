@@ -54,6 +54,19 @@ def make_rays(hs, d, n, seed):
     return np.concatenate([prim_rays, sec], axis=0)
 
 
+def sweep_tree_pins():
+    import hashlib
+
+    from pathtracer_cuda_interactive_amd import device as dev
+    out = {}
+    for name in ("scene4", "cbox", "teapot", "bunny"):
+        hs = HostScene.load(os.path.join(HERE, "scenes", name + ".pts"))
+        d = hs.finalize(PT_BVH_SORT_REFERENCE)
+        _, info = dev.build_bvh_sweep(d)
+        out[name] = {"num_shapes": int(d.num_shapes), "depth": int(info["depth"]), "md5": hashlib.md5(info["nodes"].tobytes()).hexdigest()}
+    return out
+
+
 if __name__ == "__main__":
     for sub in ("images", "rays", "bvh"):
         os.makedirs(os.path.join(HERE, sub), exist_ok=True)
@@ -104,6 +117,8 @@ if __name__ == "__main__":
             "scene4": {"shapes": 30, "nodes": 59, "depth": 6},
         },
         "topology": topo,
+        # the library's internal tree (pt_bvh_build_sweep, host code): node pool bytes, so that a change of the builder shows
+        "sweep_tree": sweep_tree_pins(),
     }
     with open(os.path.join(HERE, "pins.json"), "w") as f:
         json.dump(pins, f, indent=1)

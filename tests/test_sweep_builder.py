@@ -146,3 +146,19 @@ def _desc_with_nodes(desc, nodes, root):
     d2.root = root
     d2._keep = (nodes, desc)
     return d2
+
+
+@pytest.mark.parametrize("name", ["scene4", "cbox", "teapot", "bunny"])
+def test_sweep_trees_are_pinned(name):
+    """Node pools of the internal tree for the fixture scenes, byte for byte (tests/golden/pins.json, written by
+    make_golden_vectors.py): the builder is deterministic across runs, thread counts and builds — a change of it must show."""
+    import hashlib
+    import json
+    import os
+
+    from conftest import GOLDEN
+    pin = json.load(open(os.path.join(GOLDEN, "pins.json")))["sweep_tree"][name]
+    hs, d = load_scene(name)
+    _, info = dev.build_bvh_sweep(d)
+    assert (int(d.num_shapes), int(info["depth"])) == (pin["num_shapes"], pin["depth"])
+    assert hashlib.md5(info["nodes"].tobytes()).hexdigest() == pin["md5"]
