@@ -650,7 +650,7 @@ TraceFn pick_v2_ti(int res, bool prune, bool stats, int spec) {
 TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, int inner, int minw) {
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
-    PT_V2(32, 1004, 6)
+    PT_V2(32, 1004, 6) PT_V2(32, 1231, 6)
 #undef PT_V2
     return nullptr;
 }
@@ -691,10 +691,12 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats, bool int
         const bool lds = res == 1 || res == 2;
         if (t == 0) t = lds ? 40 : 32;
         const bool tri = S->tri_only && S->opt_specialize;
-        // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1, on the internal tree with leaves set aside (v2_inner
-        // 1000 + burst: bunny -2.2 %, dragon stand-in -3.4 %; LDS-resident scenes lose 9 % with it —
-        // profiles/r02_tune_round43_postponed_leaves.log)
-        if (i == 0) i = lds ? 162 : (internal_tree ? 1004 : 4);
+        // LDS-resident: 6 inner + 2 leaf steps; global memory: 4 + 1 on the caller's tree; on the internal tree two rounds of
+        // 3 + 1 with leaves set aside (v2_inner 1000 + burst).  Setting leaves aside: bunny -2.2 %, dragon stand-in -3.4 %
+        // against the plain 4 + 1 (LDS-resident scenes lose 9 % with it: profiles/r02_tune_round43_postponed_leaves.log); two
+        // rounds of 3 + 1 instead of one of 4 + 1: teapot -8.5 %, bunny -1.2 %, buddha stand-in -1.5 %, dragon stand-in -1.8 %
+        // (r02_tune_round48_global_thresh.log, r02_tune_round49_global_burst.log; thresholds 24 / 40 / 48 lose).
+        if (i == 0) i = lds ? 162 : (internal_tree ? 1231 : 4);
         if (i >= 1000 && !internal_tree) return nullptr;        // order-free leaf tests need the internal tree's tie handling
         if (w == 0) w = 6;
         const int spec = !tri ? 0 : (S->diffuse_only ? 2 : 1);

@@ -256,7 +256,7 @@ def test_internal_tree_is_kept_only_where_it_touches_fewer_boxes(oracle):
 @pytest.mark.gpu
 def test_leaves_set_aside_is_an_internal_tree_schedule_only(oracle):
     """Scenes in global memory on the internal tree run the burst that sets leaves aside (v2_inner 1004): leaf tests in an
-    order no tree prescribes.  Right on the internal tree (ties are settled by the caller's order whatever the test order),
+    order no tree prescribes (the default there is 1231: two rounds of 3 + 1).  Right on the internal tree (ties are settled by the caller's order whatever the test order),
     refused on the caller's tree, where the visit order IS the tie rule."""
     from pathtracer_cuda_interactive_amd import PT_ERR_INVALID_ARG, PtError
     hs, d = load_scene("teapot")
@@ -265,7 +265,7 @@ def test_leaves_set_aside_is_an_internal_tree_schedule_only(oracle):
     ds = dev.DeviceScene(d)
     try:
         ds.set_option("stats", 1)
-        for inner in (0, 1004, 4):               # 0 = automatic = 1004 here
+        for inner in (0, 1004, 1231, 4):         # 0 = automatic = 1231 here
             ds.set_option("v2_inner", inner)
             img = ds.render(p)
             assert_bit_equal(img, want, f"teapot v2_inner={inner}")
