@@ -223,6 +223,8 @@ def main():
                     help="exact traversal: the library's internal tree over the caller's leaf boxes (default; bit-identical "
                          "results) or the caller's (reference median-split) tree itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-work-frames", action="store_true",
+                    help="skip the two untimed counting frames behind config.work (profiling runs: only the timed kernel on the GPU)")
     ap.add_argument("--stub-renderer", action="store_true",
                     help="TEST HOOK: run the multi-rank control flow on CPU (gloo) with a renderer that renders nothing")
     ap.add_argument("--progressive", type=int, default=0, metavar="SPF",
@@ -317,7 +319,7 @@ def main():
     # Work the kernel really did per segment (one extra, untimed frame with the counting build of the kernel, rank 0's rows):
     # the algorithmic figures below price the REFERENCE's traversal of the REFERENCE's tree; this is what was traversed.
     work = None
-    if not stub:
+    if not stub and not args.no_work_frames:
         R.scene.set_option("stats", 1)
         R.render(params, rank, world)
         cw = R.scene.counters()

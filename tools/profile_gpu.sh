@@ -9,8 +9,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # kernel trace: the default bench command (20 steps, 3 warm-up) so that its average agrees with bench.py's own HIP-event time;
 # counter passes: 5 steps are enough (every launch is identical)
-TRACE="python3 bench.py --no-cpu-baseline $ARGS"
-BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline $ARGS"
+TRACE="python3 bench.py --no-cpu-baseline --no-work-frames $ARGS"
+BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-work-frames $ARGS"
 echo "== kernel trace" | tee $OUT/log.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE > $OUT/bench_trace.out 2>> $OUT/log.txt || exit 1
 grep '^{' $OUT/bench_trace.out | tail -1 > $OUT/bench_line.json
