@@ -696,7 +696,8 @@ TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats, bool int
         // against the plain 4 + 1 (LDS-resident scenes lose 9 % with it: profiles/r02_tune_round43_postponed_leaves.log); two
         // rounds of 3 + 1 instead of one of 4 + 1: teapot -8.5 %, bunny -1.2 %, buddha stand-in -1.5 %, dragon stand-in -1.8 %
         // (r02_tune_round48_global_thresh.log, r02_tune_round49_global_burst.log; thresholds 24 / 40 / 48 lose, so do three rounds of
-        // 3 + 1 and two of 2 + 1, and every set-aside shape on LDS-resident scenes: r02_tune_round50_more_bursts_rejected.log).
+        // 3 + 1 and two of 2 + 1, and every set-aside shape on LDS-resident scenes: r02_tune_round50_more_bursts_rejected.log; 7 / 8 waves per
+        // SIMD by register cap, with the blocks to match: +11..16 % / +28..41 % from the spills, r02_tune_round51_more_waves_rejected.log).
         if (i == 0) i = lds ? 162 : (internal_tree ? 1231 : 4);
         if (i >= 1000 && !internal_tree) return nullptr;        // order-free leaf tests need the internal tree's tie handling
         if (w == 0) w = 6;
