@@ -244,7 +244,8 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)
  * pt_scene_get_info keys: "grid", "lds_bytes", "lds_scene", "residency" (0 global, 1 LDS, 2 LDS + octant tables, 3 global + top of the tree in LDS), "top_nodes",
  * "passes", "occupancy", "blocks_per_cu", "num_cus", "bvh_depth", "scene_bytes", "num_inner_nodes", "device", "vgprs", "vgprs_pruned",
- * "fast_tree" (an internal tree exists), "fast_tree_on" (the next exact render uses it), "fast_tree_depth",
+ * "fast_tree" (an internal tree exists), "fast_tree_on" (the next render uses it), "fast_tree_is_callers" (it is the caller's own
+ * topology in internal form: the sweep tree did not win the probe), "fast_tree_depth",
  * "fast_tree_cost_permille" (probe-ray node visits, internal / caller's x 1000; 0 = none built), "stack_entries" (per lane),
  * "redo_segments" (with "stats": segments of the last frame traced on the caller's tree), "debug_reruns" (same for pt_debug_intersect). */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);

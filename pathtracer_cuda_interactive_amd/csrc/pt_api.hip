@@ -125,6 +125,7 @@ struct pt_scene {
     DevBuf<unsigned long long> ref_path;   // per primitive: its root-to-leaf turns in the caller's tree (ties on t, pt_trace.h: ref_visits_first)
     DevBuf<int32_t> ref_anc;         // per primitive and level: the inner node of the caller's tree there
     int32_t ref_levels = 0;
+    bool fast_is_callers_topology = false;   // tree[1] = the caller's own tree in internal form (the sweep tree did not win)
     DevBuf<int32_t> redo_stack;      // global-memory traversal stacks of the reference-order reruns (one column per lane of the grid)
     DevBuf<DPrim> prims;
     DevBuf<DNormals> normals;
@@ -461,12 +462,12 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             return fail(PT_ERR_BAD_SCENE, "area light refers to a shape that does not exist");
     }
     int rc;
-    for (int t = 0; t < 2; t++) {
-        if (!hosts[t]) continue;
-        const std::vector<DNode>& nodes = hosts[t]->nodes;
+    auto upload_tree = [&](int t, const TreeHost& H) -> int {
+        const std::vector<DNode>& nodes = H.nodes;
         pt_scene::Tree& T = S->tree[t];
         // 8 ray-octant copies of the node table for LDS-resident scenes: octant bit k set <=> 1/d[k] < 0, in which case
         // Hit() swaps the two slab distances of axis k (bbox.cuh:40-55); here the two planes are swapped instead.
+        T.have_oct = false;
         if (nodes.size() * 8 * sizeof(DNode) <= kOctNodeLimit) {
             std::vector<DNode> nodes_oct(nodes.size() * 8);
             for (int o = 0; o < 8; o++)
@@ -476,18 +477,23 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
                         if (o & (1 << ax)) { std::swap(n.lmin[ax], n.lmax[ax]); std::swap(n.rmin[ax], n.rmax[ax]); }
                     nodes_oct[(size_t)o * nodes.size() + k] = n;
                 }
-            if ((rc = T.nodes_oct.ensure(nodes_oct.size()))) return rc;
+            int r;
+            if ((r = T.nodes_oct.ensure(nodes_oct.size()))) return r;
             HIP_TRY(hipMemcpy(T.nodes_oct.p, nodes_oct.data(), nodes_oct.size() * sizeof(DNode), hipMemcpyHostToDevice));
             T.have_oct = true;
         }
-        if ((rc = T.nodes.ensure(nodes.size()))) return rc;
+        int r;
+        if ((r = T.nodes.ensure(nodes.size()))) return r;
         HIP_TRY(hipMemcpy(T.nodes.p, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
         T.num_nodes = (int32_t)nodes.size();
-        T.root_ref = hosts[t]->root_ref;
-        T.stack_cap = hosts[t]->stack_need + 1;                 // + the kDone sentinel at the bottom
-        T.top_avail = hosts[t]->top_avail;
-        T.depth = hosts[t]->depth;
-    }
+        T.root_ref = H.root_ref;
+        T.stack_cap = H.stack_need + 1;                         // + the kDone sentinel at the bottom
+        T.top_avail = H.top_avail;
+        T.depth = H.depth;
+        return PT_OK;
+    };
+    for (int t = 0; t < 2; t++)
+        if (hosts[t] && (rc = upload_tree(t, *hosts[t]))) return rc;
     S->have_fast = have_fast;
     if ((rc = S->prims.ensure(prims.size()))) return rc;
     if ((rc = S->normals.ensure(normals.size()))) return rc;
@@ -526,11 +532,25 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         unsigned long long v[2] = {0, 0};
         HIP_TRY(hipMemcpy(v, visits.p, sizeof(v), hipMemcpyDeviceToHost));
         S->fast_cost_permille = v[0] ? (int64_t)((1000ull * v[1] + v[0] / 2) / v[0]) : 1000;
-        if (!(v[1] * 100ull < v[0] * 90ull)) {              // not at least 10 % fewer boxes: not worth a second tree
+        if (!(v[1] * 100ull < v[0] * 90ull)) {              // not at least 10 % fewer boxes: the sweep tree is not worth having
             S->have_fast = false;
             S->tree[1].nodes.release();
             S->tree[1].nodes_oct.release();
             S->tree[1].have_oct = false;
+            // ... but the way the internal tree is TRAVERSED still is, for scenes in global memory: left child first with the
+            // children ordered for a short stack, leaves set aside, ties settled in place.  So the caller's own topology becomes the
+            // internal tree (a caller who hands in a tree as good as the sweep tree: 5.43 -> 4.9 ms on bunny,
+            // profiles/r02_device_bvh_build.log).
+            const bool global_scene = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref.nodes.size() * sizeof(DNode) > kLdsSceneLimit;
+            if (global_scene) {
+                TreeHost own;
+                bool own_nested = true;
+                if (convert_tree(d->nodes, d->num_nodes, d->root, N, own, nullptr, &own_nested, true) == PT_OK && own_nested) {
+                    if ((rc = upload_tree(1, own))) return rc;
+                    S->have_fast = true;
+                    S->fast_is_callers_topology = true;
+                }
+            }
         }
     }
     if (S->have_fast) {
@@ -1056,6 +1076,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "fast_tree") *value = S->have_fast ? 1 : 0;             // an internal tree exists (the caller's tree is nested)
     else if (k == "debug_reruns") *value = S->info_debug_reruns;          // rays the last pt_debug_intersect reran in reference order
     else if (k == "fast_tree_cost_permille") *value = S->fast_cost_permille;   // summed inner-box area, internal tree / caller's tree x 1000 (0: none built)
+    else if (k == "fast_tree_is_callers") *value = (S->have_fast && S->fast_is_callers_topology) ? 1 : 0;
     else if (k == "fast_tree_on") *value = which_tree(S, PT_TRAVERSAL_EXACT);    // ... and the next exact render traverses it
     else if (k == "fast_tree_depth") *value = S->have_fast ? S->tree[1].depth : 0;
     else if (k == "scene_bytes") *value = S->scene_bytes;

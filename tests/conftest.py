@@ -68,7 +68,13 @@ def assert_work_counters(ds, c, cnt, oracle, d, p, what=""):
     component leave the internal tree at once and are rerun on the caller's (info redo_segments): they are the slack."""
     assert (c.paths, c.segments) == (cnt.paths, cnt.segments), what
     from pathtracer_cuda_interactive_amd import device as dev
-    if ds.info("fast_tree") and ds.info("fast_tree_on"):
+    if ds.info("fast_tree") and ds.info("fast_tree_on") and ds.info("fast_tree_is_callers"):
+        # the internal tree is the caller's own topology (the sweep tree did not win the probe): same nodes, visited in another
+        # order — the counts are the caller's tree's
+        slack = ds.info("redo_segments")
+        assert abs(c.node_visits - cnt.inner_pops) <= 256 * slack, (what, c.node_visits, cnt.inner_pops, slack)
+        assert abs(c.leaf_tests - (cnt.leaf_tri + cnt.leaf_sphere)) <= 256 * slack, what
+    elif ds.info("fast_tree") and ds.info("fast_tree_on"):
         d_int, _ = dev.build_bvh_sweep(d)
         _, cnt_int = oracle.render(d_int, p)
         slack = ds.info("redo_segments")

@@ -32,9 +32,14 @@ def main():
             d2, info = dev.build_bvh_device(d, m)
             info["wall_ms"] = (time.perf_counter() - t0) * 1e3   # uploads + build + copy of the nodes back to the host
             trees.append((label, d2, info))
+        t0 = time.perf_counter()
+        d3, info3 = dev.build_bvh_sweep(d)                       # the internal tree's builder (host threads)
+        info3["wall_ms"] = (time.perf_counter() - t0) * 1e3
+        trees.append(("host full-sweep SAH (pt_bvh_build_sweep)", d3, info3))
         base_img = None
         for label, dd, info in trees:
             ds = dev.DeviceScene(dd)
+            ds.set_option("fast_tree", 0)                        # the tree as handed in ...
             ds.set_option("stats", 1)
             img = ds.render(p)
             c = ds.counters()
@@ -43,12 +48,18 @@ def main():
             for _ in range(5):
                 ds.render(p)
                 ts.append(ds.counters().kernel_ms)
+            ds.set_option("fast_tree", 1)                        # ... and what pt_scene_create makes of it
+            ti = []
+            for _ in range(5):
+                ds.render(p)
+                ti.append(ds.counters().kernel_ms)
+            internal = f"with the internal tree over it {np.median(ti):8.3f} ms" if ds.info("fast_tree_on") else "no internal tree kept"
             if base_img is None:
                 base_img = img
             diff_px = int((np.abs(img - base_img).max(axis=2) > 0).sum())
-            print(f"{name:15s} {label:32s} prims {dd.num_shapes:8d} depth {info['depth']:3d} build {info['build_ms']:9.2f} ms (wall {info['wall_ms']:9.1f} ms) "
+            print(f"{name:15s} {label:42s} prims {dd.num_shapes:8d} depth {info['depth']:3d} build {info['build_ms']:9.2f} ms (wall {info['wall_ms']:9.1f} ms) "
                   f"inner visits/segment {c.node_visits / c.segments:6.2f} leaf tests/segment {c.leaf_tests / c.segments:5.2f} "
-                  f"frame {np.median(ts):8.3f} ms  lds {ds.info('lds_bytes'):6d} top {ds.info('top_nodes'):4d} residency {ds.info('residency')}  pixels differing from the reference tree: {diff_px}",
+                  f"frame {np.median(ts):8.3f} ms ({internal})  lds {ds.info('lds_bytes'):6d} top {ds.info('top_nodes'):4d} residency {ds.info('residency')}  pixels differing from the reference tree: {diff_px}",
                   flush=True)
             ds.close()
 
