@@ -44,7 +44,8 @@ WORKLOADS = {
 
 
 def cpu_baseline(desc, params, name):
-    """The oracle (CPU port of the same algorithm) timed on this box's host cores — reported, never shipped."""
+    """The oracle (CPU port of the same algorithm) timed on this box's host cores — reported, never shipped.
+    Returns (cpu_baseline dict, oracle image of the sampled rows, row stride k of the sample)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_binding as ob
     ob.build()
@@ -57,13 +58,26 @@ def cpu_baseline(desc, params, name):
         q.row_begin, q.row_end, q.row_stride = 0, params.height, k
         sample = f"every {k}th row of the {params.width}x{params.height} frame at spp={params.spp} ({q.num_rows()} rows)"
     else:
+        k = 1
         q = params
         sample = f"full frame {params.width}x{params.height} spp={params.spp}"
-    _, cnt = ob.render(desc, q, threads=ob.usable_cores())
+    img, cnt = ob.render(desc, q, threads=ob.usable_cores())
     wall = time.perf_counter() - t0
-    return {"value": round(cnt.segments / cnt.seconds / 1e6, 3), "unit": "Msamples/s", "cores": int(cnt.threads_used),
-            "kind": "port", "sample": sample, "seconds": round(cnt.seconds, 3), "wall_seconds": round(wall, 3),
-            "segments": int(cnt.segments), "bytes_per_segment_measured": round(cnt.bytes_per_segment(), 1)}
+    return ({"value": round(cnt.segments / cnt.seconds / 1e6, 3), "unit": "Msamples/s", "cores": int(cnt.threads_used),
+             "kind": "port", "sample": sample, "seconds": round(cnt.seconds, 3), "wall_seconds": round(wall, 3),
+             "segments": int(cnt.segments), "bytes_per_segment_measured": round(cnt.bytes_per_segment(), 1)}, img, k)
+
+
+def parity_rows(frame, oracle_rows, k):
+    """The LAST TIMED GPU frame against the oracle's rows of the same frame (rows 0, k, 2k, ... at the config's full spp): every
+    float compared bit for bit.  The oracle is the checker here, never the thing measured."""
+    gpu = frame[::k].detach().cpu().numpy()
+    same = gpu.shape == oracle_rows.shape and bool((gpu.view(np.uint32) == oracle_rows.view(np.uint32)).all())
+    out = {"rows": int(oracle_rows.shape[0]), "row_stride": int(k), "bit_identical": same}
+    if not same and gpu.shape == oracle_rows.shape:
+        out["differing_pixels"] = int((gpu.view(np.uint32) != oracle_rows.view(np.uint32)).any(axis=2).sum())
+        out["max_abs_diff"] = float(np.abs(gpu - oracle_rows).max())
+    return out
 
 
 # README.md FPS of the reference on an RTX 3080 at its UI default of 2 samples per frame, 640x480, INCLUDING per-frame CPU
@@ -157,13 +171,19 @@ class StubRenderer:
         def info(self, key):
             return 1 if key == "passes" else 0
 
+        def set_option(self, key, value):
+            pass
+
+        def frame_times(self, n):
+            return np.full(n, self.c.kernel_ms), np.full(n, self.c.resolve_ms)
+
         def close(self):
             pass
 
     def __init__(self, desc, hs):
         self.scene = self._Scene()
 
-    def render(self, params, rank, world):
+    def render(self, params, rank, world, force_collective=False):
         import torch
 
         from pathtracer_cuda_interactive_amd import distributed as D
@@ -173,43 +193,63 @@ class StubRenderer:
             self.scene.c.paths = int(rows.numel()) * q.width * q.spp
             self.scene.c.segments = 2 * self.scene.c.paths
             return rows[:, None, None].expand(-1, q.width, 3).contiguous()
-        return D.render_sharded(render_rows, params, rank, world)
+        return D.render_sharded(render_rows, params, rank, world, force_collective=force_collective)
 
     def close(self):
         pass
 
 
+L1_TAG_LOOKUPS_MICROBENCH = 1.4    # L1 tag lookups per cycle per CU that tools/microbench/gather_nodes.hip reaches with this access
+                                   # shape (a dependent chain of divergent 16-B loads; profiles/r02_microbench_gather.log)
+
+
 def physical_roofline(scene, traversal, lds_scene, k_ms, launches):
     """The bound that physically limits the trace kernel, as a fraction <= 1:
       LDS-resident scenes  -> VALU lane throughput:  frac = (SQ_INSTS_VALU / t) / (1024 SIMDs x 2.4 GHz / 2 cycles) x lane utilisation
-      scenes in global mem -> L2-miss (fabric) bandwidth:  frac = (EA read bytes + write bytes) / t / 8 TB/s
+      scenes in global mem -> the vector L1's tag-lookup rate for divergent loads (one lookup per active lane and 16-B load):
+                              frac = TCP_TOTAL_CACHE_ACCESSES / kernel cycles / 256 CUs / 1.4 (the rate the access shape reaches alone);
+                              beside it the L2-miss (fabric) bandwidth:  (EA read bytes + write bytes) / t / 8 TB/s
     Instruction and byte counts per launch come from the committed rocprofv3 PMC run of the same command
     (profiles/rNN_<scene>_pmc.json — a launch of this config executes the same work every time); t = this run's
-    HIP-event kernel time of one frame, which is `launches` trace_kernel launches when the frame runs in sample passes."""
+    HIP-event kernel time of one frame, which is `launches` trace_kernel launches when the frame runs in sample passes.
+    Returns flat scalars only (they are merged into the top level of `roofline`)."""
     import glob
     cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{scene}_pmc.json")))
     if traversal != "exact" or not cands:
-        return None
+        return {}
     prof = json.load(open(cands[-1]))
     c, dv = prof.get("counters_mean_per_launch", {}), prof.get("derived", {})
     t = k_ms * 1e-3
-    src = os.path.relpath(cands[-1], REPO)
-    if lds_scene:
-        if "SQ_INSTS_VALU" not in c or "valu_lane_utilization" not in dv:
-            return None
+    out = {"pmc_source": os.path.relpath(cands[-1], REPO)}
+    for k_src, k_dst in (("valu_lane_utilization", "lane_utilization"), ("valu_issue_busy", "valu_issue_busy_profiled"),
+                         ("sq_wait_any_share_of_wave_cycles", "waves_waiting_share"), ("lds_bank_conflict_share", "lds_bank_conflict_share"),
+                         ("l2_hit_rate", "l2_hit_rate")):
+        if k_src in dv:
+            out[k_dst] = round(float(dv[k_src]), 4)
+    if "SQ_INSTS_VALU" in c:
         peak = 1024 * 2.4e9 / 2.0                       # wave64 VALU instructions per second: 2 cycles each on a SIMD-32
-        issue = c["SQ_INSTS_VALU"] * launches / t / peak
-        return {"bound": "valu", "frac": round(issue * dv["valu_lane_utilization"], 4),
-                "valu_issue_frac_of_peak": round(issue, 4), "lane_utilization": round(dv["valu_lane_utilization"], 4),
-                "formula": "SQ_INSTS_VALU / kernel_s / (1024 x 2.4e9 / 2) x (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))",
-                "source": src}
-    if "l2_miss_bytes_per_launch" not in dv:
-        return None
-    gbs = dv["l2_miss_bytes_per_launch"] * launches / t / 1e9
-    return {"bound": "l2_miss_bw", "frac": round(gbs / HBM_PEAK_GBS, 4), "achieved_GBps": round(gbs, 1), "peak_GBps": HBM_PEAK_GBS,
-            "formula": "(32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B [TCC_EA0_RDREQ*] + 1024 x WRITE_SIZE) / kernel_s / 8e12; "
-                       "bytes that leave the L2 are served by the Infinity Cache or by HBM",
-            "source": src}
+        out["valu_issue_frac"] = round(c["SQ_INSTS_VALU"] * launches / t / peak, 4)
+    if lds_scene:
+        if "valu_issue_frac" in out and "lane_utilization" in out:
+            out["physical_bound"] = "valu_lane_throughput"
+            out["physical_frac"] = round(out["valu_issue_frac"] * out["lane_utilization"], 4)
+            out["physical_formula"] = "SQ_INSTS_VALU / kernel_s / (1024 x 2.4e9 / 2) x SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"
+        return out
+    if "l2_miss_bytes_per_launch" in dv:
+        gbs = dv["l2_miss_bytes_per_launch"] * launches / t / 1e9
+        out["l2_miss_GBps"] = round(gbs, 1)
+        out["l2_miss_frac_of_hbm_peak"] = round(gbs / HBM_PEAK_GBS, 4)
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        rate = c["TCP_TOTAL_CACHE_ACCESSES_sum"] * launches / (t * 2.4e9) / 256.0
+        out["l1_tag_lookups_per_cycle_per_cu"] = round(rate, 4)
+        out["physical_bound"] = "l1_tag_lookup_rate"
+        out["physical_frac"] = round(rate / L1_TAG_LOOKUPS_MICROBENCH, 4)
+        out["physical_formula"] = "TCP_TOTAL_CACHE_ACCESSES / (kernel_s x 2.4e9) / 256 CUs / 1.4 lookups per cycle per CU (gather microbenchmark)"
+    elif "l2_miss_frac_of_hbm_peak" in out:
+        out["physical_bound"] = "l2_miss_bw"
+        out["physical_frac"] = out["l2_miss_frac_of_hbm_peak"]
+        out["physical_formula"] = "(32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B [TCC_EA0_RDREQ*] + 1024 x WRITE_SIZE) / kernel_s / 8e12"
+    return out
 
 
 def main():
@@ -225,6 +265,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-work-frames", action="store_true",
                     help="skip the two untimed counting frames behind config.work (profiling runs: only the timed kernel on the GPU)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="N=1 only: run every frame through the N>1 path — a one-rank nccl (RCCL) group, gather + de-interleave — "
+                         "to measure what that step costs per frame")
     ap.add_argument("--stub-renderer", action="store_true",
                     help="TEST HOOK: run the multi-rank control flow on CPU (gloo) with a renderer that renders nothing")
     ap.add_argument("--progressive", type=int, default=0, metavar="SPF",
@@ -252,12 +295,18 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_gather = bool(args.force_gather) and world == 1
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_gather and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if stub:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
 
     if not os.path.exists(_build.HIP_LIB) or not os.path.exists(_build.HOST_LIB):
@@ -281,14 +330,13 @@ def main():
     R = StubRenderer(desc, hs) if stub else D.ShardedRenderer(desc)
     if not stub and args.tree == "caller":
         R.scene.set_option("fast_tree", 0)
-    kernel_ms, resolve_ms, segs, paths = [], [], [], []
+    # The timed loop enqueues frame after frame on the stream (N>1: each followed by the gather) with NO host sync inside: the
+    # library keeps the HIP events of the last `steps` render calls (option "timing_frames"), read after the closing fence.
+    # Every frame renders the same streams, so its work counters are the last frame's.
+    R.scene.set_option("timing_frames", max(args.steps, 1))
 
-    def step(record):
-        frame = R.render(params, rank, world)
-        c = R.scene.counters()                           # syncs this rank's stream; also the HIP-event kernel time
-        if record:
-            kernel_ms.append(c.kernel_ms); resolve_ms.append(c.resolve_ms); segs.append(c.segments); paths.append(c.paths)
-        return frame
+    def step():
+        return R.render(params, rank, world, force_collective=force_gather)
 
     def fence():
         if not stub:
@@ -299,14 +347,23 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     fence()
+    c_warm = R.scene.counters() if args.warmup else None
     t0 = time.perf_counter()
     frame = None
     for _ in range(args.steps):
-        frame = step(True)
+        frame = step()
     fence()
     elapsed = time.perf_counter() - t0
+    c_last = R.scene.counters()
+    if c_warm is not None and (c_warm.segments, c_warm.paths) != (c_last.segments, c_last.paths):
+        raise SystemExit("bench.py: two frames of the same configuration traced different work")
+    kernel_ms, resolve_ms = R.scene.frame_times(args.steps)
+    if len(kernel_ms) != args.steps:
+        raise SystemExit("bench.py: the library did not keep the events of every timed frame")
+    segs = [c_last.segments] * args.steps
+    paths = [c_last.paths] * args.steps
 
     t = torch.tensor([elapsed, float(sum(segs)), float(sum(paths)), float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
     if world > 1:
@@ -349,17 +406,31 @@ def main():
             traffic = json.load(open(tpath)).get(f"{args.scene}:{args.traversal}")   # PMC bytes per trace_kernel launch
             if traffic is not None:
                 traffic = int(traffic * passes)         # "launch" here = one frame = `passes` trace_kernel launches
-        # counters of the committed rocprofv3 PMC run of this config (profiles/, tools/profile_gpu.sh): static context, not re-measured here
-        pmc = None
-        import glob
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{args.scene}_pmc.json")))
-        if args.traversal == "exact" and cands:
-            dv = json.load(open(cands[-1])).get("derived", {})
-            pmc = {k: round(float(dv[k]), 4) for k in ("valu_issue_busy", "valu_lane_utilization", "sq_wait_any_share_of_wave_cycles",
-                                                      "lds_bank_conflict_share", "l2_hit_rate") if k in dv}
-            pmc["source"] = os.path.relpath(cands[-1], REPO)
         lds_scene = bool(R.scene.info("lds_scene"))
-        physical = None if stub else physical_roofline(args.scene, args.traversal, lds_scene, k_ms, passes)
+        # flat scalars from the committed rocprofv3 PMC run of this config (profiles/, tools/profile_gpu.sh) and this run's kernel time
+        physical = {} if stub else physical_roofline(args.scene, args.traversal, lds_scene, k_ms, passes)
+        work_done_frac = None
+        if work and "callers_tree_inner_visits_per_segment" in work:
+            # "work avoided is not bandwidth achieved" (SURVEY §8d): the algorithmic figure with the inner visits this run really
+            # made (60 B each in the reference layout) instead of the caller's tree's
+            b_done = wl["bytes_per_segment"] - 60.0 * (work["callers_tree_inner_visits_per_segment"] - work["inner_visits_per_segment"])
+            work_done_frac = round(b_done * seg_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    # SURVEY §8d's fields above, exactly as defined there: ALGORITHMIC bytes of the reference layout at the
+                    # reference's visit counts per second against the HBM peak — not a physical fraction (those bytes are served
+                    # by LDS / L1 / L2, and the internal tree avoids part of them).  The physical bound follows, as scalars.
+                    "frac_kind": "algorithmic (SURVEY 8d), NOT physical: see physical_frac",
+                    "work_done_frac": work_done_frac,
+                    "inner_visits_per_segment": work.get("inner_visits_per_segment") if work else None,
+                    "callers_tree_inner_visits_per_segment": work.get("callers_tree_inner_visits_per_segment") if work else None,
+                    "leaf_tests_per_segment": work.get("leaf_tests_per_segment") if work else None,
+                    "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                    "kernel_launches_per_step": passes,
+                    "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
+                    "note": ("scene staged in LDS (%d B): physical bound = VALU lane throughput, DESIGN.md 7" % R.scene.info("scene_bytes")) if lds_scene else
+                            ("scene (%.1f MB) served by L1/L2/Infinity Cache: physical bound = L1 tag-lookup rate, DESIGN.md 7" % (R.scene.info("scene_bytes") / 1e6))}
+        roofline.update(physical)
         out = {
             "metric": "Msamples/sec (rays x spp x bounces = intersect() calls per second), " + wl["label"].split(" (")[0],
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -381,33 +452,25 @@ def main():
                        # same closest hits (ties in the caller's visit order), fewer inner visits; "caller" = --tree caller
                        "tree": ("stub" if stub else "internal" if R.scene.info("fast_tree_on") else "caller"),
                        "stack_entries": 0 if stub else int(R.scene.info("stack_entries")),
+                       "host_sync_per_step": False, "forced_gather": force_gather,
                        "work": work,
                        "frame_mean": round(float(frame.mean().item()), 6)},
-            # SURVEY §8d's fields, exactly as defined there: ALGORITHMIC bytes of the reference layout per second against the HBM
-            # peak (can exceed 1: those bytes are served by LDS / L1 / L2, not by HBM).  `physical` names the bound that really
-            # limits this kernel and gives a fraction <= 1 of it; `traffic` = measured L2-miss bytes per frame (PMC).
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "physical": physical,
-                         "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_launches_per_step": passes, "pmc": pmc,
-                         "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
-                         # "work avoided is not bandwidth achieved" (SURVEY §8d): the same figure with the inner visits this run
-                         # really made (60 B each in the reference layout) instead of the caller's tree's
-                         "work_done": (None if not (work and "callers_tree_inner_visits_per_segment" in work) else (lambda b: {
-                             "bytes_per_segment": round(b, 1), "achieved": round(b * seg_launch / (k_ms * 1e-3) / 1e9, 1),
-                             "frac": round(b * seg_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})(
-                             wl["bytes_per_segment"] - 60.0 * (work["callers_tree_inner_visits_per_segment"] - work["inner_visits_per_segment"]))),
-                         "note": ("working set is staged in LDS (scene %d B): HBM is NOT the physical bound, frac>1 is possible; "
-                                  "the physical bound is VALU lane throughput, see `physical` and DESIGN.md §7" % R.scene.info("scene_bytes")) if lds_scene else
-                                 "working set (%.1f MB) is served by L2/Infinity Cache: the physical bound is the L2-miss path, see `physical` and DESIGN.md §7" % (R.scene.info("scene_bytes") / 1e6)},
+            "roofline": roofline,
         }
         if stub:
             out["stub"] = True
             out["config"]["frame_rows_ok"] = bool((frame[:, 0, 0] == torch.arange(wl["h"], dtype=torch.float32)).all())
         if world == 1 and not args.no_cpu_baseline and not stub:
-            out["cpu_baseline"] = cpu_baseline(desc, hs.render_params(wl["w"], wl["h"], wl["spp"]), args.scene)
+            # the oracle's rows of the very frame that was timed: the CPU baseline AND the checker of the last timed GPU frame
+            out["cpu_baseline"], oracle_rows, k = cpu_baseline(desc, hs.render_params(wl["w"], wl["h"], wl["spp"]), args.scene)
+            out["parity_rows"] = parity_rows(frame, oracle_rows, k) if args.traversal == "exact" else None
         print(json.dumps(out), flush=True)
+        if out.get("parity_rows") and not out["parity_rows"]["bit_identical"]:
+            sys.stderr.write("bench.py: the timed GPU frame differs from the oracle: %r\n" % (out["parity_rows"],))
+            R.close()
+            raise SystemExit(3)
     R.close()
-    if world > 1:
+    if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -194,6 +194,12 @@ int pt_render_accumulate(pt_scene* scene, const pt_render_params* p, float* accu
 
 int pt_get_counters(pt_scene* scene, pt_counters* out);   /* synchronises the scene's last stream */
 
+/* HIP-event times of the last render calls on the scene, oldest first: kernel_ms[k] / resolve_ms[k] of up to max_frames calls,
+ * *n_out of them written.  The library keeps the events of the last "timing_frames" calls (option, default 1), so a caller
+ * may enqueue many frames on a stream without a host sync in between and read every frame's kernel time afterwards
+ * (bench.py's timed loop).  Synchronises the scene's last stream. */
+int pt_get_frame_times(pt_scene* scene, int max_frames, double* kernel_ms, double* resolve_ms, int* n_out);
+
 /* BVH construction on the device — an alternative producer of `pt_scene_desc.nodes` to the host's
  * construct_bvh (bvh.cu:16-54: object-median split, O(N log^2 N), 10-57 s start-up in README.md:123,132).
  *   PT_BVH_DEVICE_LBVH  Morton order + Karras hierarchy
@@ -238,7 +244,8 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  *   "xcd_regions"   0 (default) 8 row bands with XCD affinity, 1 = a single work queue
  *   "item_order"    1 (default) a band is worked through row by row (all samples of a row first), 0 = sample by sample
  *   "force_global"  1 = never stage the scene in LDS
- *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query)
+ *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query; at most 32)
+ *   "timing_frames" render calls whose HIP events are kept for pt_get_frame_times (1 .. 4096, default 1)
  *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 8 GiB); larger jobs run in sample passes
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)

@@ -110,9 +110,10 @@ struct pt_scene {
     int device = 0;
     int num_cus = 0;
     size_t lds_per_block_max = 0;
-    // scene arrays.  Two layouts of the hierarchy: tree[0] = the caller's tree (the reference's, bvh.cu:16-54), tree[1] = a
-    // surface-area-cost tree over the SAME leaf boxes built on the device at create time (pt_bvh_build.hip).  Exact traversal
-    // runs on tree[1] and falls back to tree[0] for the rays whose result depends on the visit order (see launch_render).
+    // scene arrays.  Two layouts of the hierarchy: tree[0] = the caller's tree (the reference's, bvh.cu:16-54), tree[1] = the
+    // library's internal tree over the SAME leaf boxes, made at create time (validate_and_build: the full-sweep surface-area
+    // tree of pt_tree_sweep.h / pt_sweep_build.hip, or the caller's own topology in internal form).  Exact traversal runs on
+    // tree[1] and falls back to tree[0] for the rays whose result depends on the visit order (see launch_render).
     struct Tree {
         DevBuf<DNode> nodes;
         DevBuf<DNode> nodes_oct;     // [8][num_nodes] octant-specialised copies (small scenes only)
@@ -164,12 +165,18 @@ struct pt_scene {
     // info of last launch
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0, info_debug_reruns = 0, fast_cost_permille = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
-    std::vector<PassEvents> pass_events;                         // pool, reused from frame to frame
-    size_t passes_timed = 0;                                     // events of the last frame: pass_events[0 .. passes_timed)
+    // HIP events of the last `opt_timing_frames` render calls (a ring; default 1): a caller that enqueues frame after frame
+    // without a host sync in between — bench.py's timed loop — reads every frame's kernel time afterwards (pt_get_frame_times)
+    struct FrameRec { std::vector<PassEvents> ev; size_t passes = 0; };
+    std::vector<FrameRec> frames;
+    uint64_t frame_seq = 0;                                      // render calls so far; the last one sits in frames[(frame_seq - 1) % size]
+    int64_t opt_timing_frames = 1;
+    const FrameRec* last_frame() const { return frame_seq && !frames.empty() ? &frames[(frame_seq - 1) % frames.size()] : nullptr; }
     void drop_events() {
-        for (auto& pe : pass_events) { (void)hipEventDestroy(pe.t0); (void)hipEventDestroy(pe.t1); (void)hipEventDestroy(pe.r1); }
-        pass_events.clear();
-        passes_timed = 0;
+        for (auto& f : frames)
+            for (auto& pe : f.ev) { (void)hipEventDestroy(pe.t0); (void)hipEventDestroy(pe.t1); (void)hipEventDestroy(pe.r1); }
+        frames.clear();
+        frame_seq = 0;
     }
     // launch configuration of the last kernel variant used (occupancy query and attribute call are not free per frame)
     const void* cfg_fn = nullptr;
@@ -437,7 +444,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
                 built = false;
             }
             bool fnested = true;
-            have_fast = built && convert_tree(fnodes.data(), d->num_nodes, froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
+            have_fast = built && convert_tree(fnodes.data(), (int)fnodes.size(), froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
         }
     }
     const TreeHost* hosts[2] = {&ref, have_fast ? &fast : nullptr};
@@ -581,6 +588,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             // no room for the tables (num_shapes x depth words): the scene simply keeps to the caller's tree
             (void)hipGetLastError();
             S->have_fast = false;
+            S->fast_is_callers_topology = false;
             S->ref_path.release(); S->ref_anc.release();
             S->tree[1].nodes.release(); S->tree[1].nodes_oct.release(); S->tree[1].have_oct = false;
         } else {
@@ -693,7 +701,7 @@ TraceFn pick_kernel_nee(int res, bool stats, int spec) {
 // The tree a render traverses: the internal tree on the default kernel where scene creation kept one (see launch_render), the
 // caller's tree otherwise.  Pruned traversal (opt-in, tolerance semantics: DESIGN.md §6) takes the internal tree as well — left
 // child first like the exact one, so that its short stacks hold; bunny 7.55 -> 3.89 ms, no pixel moved.
-int which_tree(const pt_scene* S, int traversal) {
+int which_tree(const pt_scene* S) {
     return (S->have_fast && S->opt_fast_tree && S->opt_kernel == 2) ? 1 : 0;
 }
 
@@ -737,6 +745,16 @@ int read_slot_sums(const pt_scene* S, unsigned long long* out) {
     return PT_OK;
 }
 
+// Blocks of a trace launch: every resident slot of the device, or fewer when there is not enough work to fill them.
+int launch_grid(int num_cus, int blocks_per_cu, uint64_t work_items) {
+    const uint64_t blocks_needed = (work_items + kBlock - 1) / kBlock;
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)num_cus * (uint64_t)blocks_per_cu, blocks_needed));
+}
+// Lanes (= global-memory stack columns of the reference-order reruns) of that launch.
+size_t redo_stack_lanes(int num_cus, int blocks_per_cu, uint64_t work_items) {
+    return (size_t)launch_grid(num_cus, blocks_per_cu, work_items) * kBlock;
+}
+
 struct RowSel {
     int begin, step, count;
 };
@@ -776,7 +794,13 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     S->last_stream = stream;
     S->have_timing = false;
     S->info_passes = 0;
-    S->passes_timed = 0;
+    {   // this call's slot of the timing ring
+        const size_t ring = (size_t)std::max<int64_t>(1, S->opt_timing_frames);
+        if (S->frames.size() != ring) { S->drop_events(); S->frames.resize(ring); }
+    }
+    pt_scene::FrameRec& frec = S->frames[S->frame_seq % S->frames.size()];
+    frec.passes = 0;
+    S->frame_seq++;
     if (rows.count == 0) return PT_OK;
 
     const uint64_t npix = (uint64_t)rows.count * (uint64_t)p->width;
@@ -811,7 +835,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     // reference's way: two valid hits with equal t (the first one VISITED wins, scene.h:270) are ordered by one box test in
     // the caller's tree (pt_trace.h: ref_visits_first); rays with a zero direction component (1/d infinite: the monotonicity
     // argument of validate_and_build does not cover 0 * inf) are traced on the caller's tree in reference order.
-    const int which = which_tree(S, traversal);
+    const int which = which_tree(S);
     const int res = scene_residency(S, which);
     const bool lds_scene = res == 1 || res == 2;
     const LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel == 2, which);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
@@ -842,8 +866,10 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     S->info_lds_scene = lds_scene;
 
     if (which == 1) {
-        // one global-memory stack column per lane of the grid for the reruns (rare: latency does not matter)
-        const size_t lanes = (size_t)S->num_cus * 8 * kBlock;
+        // one global-memory stack column per lane of the LARGEST grid this call launches (pass 0 traces the most samples) for
+        // the reruns (rare: latency does not matter).  Sized from the grid, not from an assumed blocks-per-CU: `blocks_per_cu`
+        // is a caller's option and the kernel indexes the buffer by blockIdx (pt_kernels.h: redo_stk).
+        const size_t lanes = redo_stack_lanes(S->num_cus, bpc, npix * spp_pass);
         if ((rc = S->redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
     }
     select_tree(S, which, which == 1);
@@ -878,8 +904,9 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
             rd.div_npix_last = make_fastdiv((uint32_t)std::max(rest, 1) * (uint32_t)p->width);
         }
 
-        const uint64_t blocks_needed = (rd.total_work + kBlock - 1) / kBlock;
-        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)S->num_cus * bpc, blocks_needed));
+        const int grid = launch_grid(S->num_cus, bpc, rd.total_work);
+        if (which == 1 && (size_t)grid * kBlock * (size_t)S->tree[0].stack_cap > S->redo_stack.n)
+            return fail(PT_ERR_DEVICE, "internal error: rerun stacks smaller than the grid");
         S->info_grid = grid;
         // chunk: work items a wave reserves per atomic.  Big launches (a wave traces >= 2048 items): 128 — the waves of a
         // launch run dry within two paths' time of each other instead of four (cbox -1.9 %, bunny -0.9 % against 256; 64
@@ -891,15 +918,15 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
                  : per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
         if (S->opt_chunk > 0) rd.chunk = (uint32_t)std::min<int64_t>(kMaxChunk, std::max<int64_t>(64, (S->opt_chunk / 64) * 64));
 
-        if (S->pass_events.size() <= (size_t)pass) {
+        if (frec.ev.size() <= (size_t)pass) {
             pt_scene::PassEvents fresh{};
             hipError_t ee = hipEventCreate(&fresh.t0);
             if (ee == hipSuccess && (ee = hipEventCreate(&fresh.t1)) != hipSuccess) (void)hipEventDestroy(fresh.t0);
             if (ee == hipSuccess && (ee = hipEventCreate(&fresh.r1)) != hipSuccess) { (void)hipEventDestroy(fresh.t0); (void)hipEventDestroy(fresh.t1); }
             if (ee != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(ee));
-            S->pass_events.push_back(fresh);
+            frec.ev.push_back(fresh);
         }
-        const pt_scene::PassEvents pe = S->pass_events[pass];
+        const pt_scene::PassEvents pe = frec.ev[pass];
         if (pass > 0) HIP_TRY(hipMemsetAsync(S->ctl.p, 0, kWorkBytes, stream));
         HIP_TRY(hipEventRecord(pe.t0, stream));
         hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
@@ -925,9 +952,24 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(pe.r1, stream));
         S->info_passes++;
-        S->passes_timed = (size_t)pass + 1;
+        frec.passes = (size_t)pass + 1;
     }
     S->have_timing = true;
+    return PT_OK;
+}
+
+// HIP-event times of one recorded render call, summed over its sample passes (the events must have completed).
+int frame_times(const pt_scene::FrameRec& f, double* kernel_ms, double* resolve_ms) {
+    double t = 0, r = 0;
+    for (size_t k = 0; k < f.passes; k++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, f.ev[k].t0, f.ev[k].t1));
+        t += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, f.ev[k].t1, f.ev[k].r1));
+        r += ms;
+    }
+    *kernel_ms = t;
+    *resolve_ms = r;
     return PT_OK;
 }
 
@@ -1013,26 +1055,37 @@ int pt_get_counters(pt_scene* S, pt_counters* out) {
     int rc = read_slot_sums(S, c);
     if (rc) return rc;
     out->paths = c[0]; out->segments = c[1]; out->node_visits = c[2]; out->leaf_tests = c[3];
-    if (S->have_timing) {
-        double t = 0, r = 0;
-        for (size_t k = 0; k < S->passes_timed; k++) {
-            const pt_scene::PassEvents& pe = S->pass_events[k];
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, pe.t0, pe.t1));
-            t += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, pe.t1, pe.r1));
-            r += ms;
-        }
-        out->kernel_ms = t;
-        out->resolve_ms = r;
+    if (S->have_timing && S->last_frame()) {
+        int rc2 = frame_times(*S->last_frame(), &out->kernel_ms, &out->resolve_ms);
+        if (rc2) return rc2;
     }
+    return PT_OK;
+}
+
+int pt_get_frame_times(pt_scene* S, int max_frames, double* kernel_ms, double* resolve_ms, int* n_out) {
+    if (!S || !kernel_ms || !resolve_ms || !n_out || max_frames < 0) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    *n_out = 0;
+    DeviceGuard guard;
+    { int grc = guard.enter(S->device); if (grc) return grc; }
+    HIP_TRY(hipStreamSynchronize(S->last_stream));
+    const uint64_t have = std::min<uint64_t>(S->frame_seq, S->frames.size());
+    const int n = (int)std::min<uint64_t>(have, (uint64_t)max_frames);
+    for (int k = 0; k < n; k++) {                        // oldest first
+        const pt_scene::FrameRec& f = S->frames[(S->frame_seq - (uint64_t)n + (uint64_t)k) % S->frames.size()];
+        int rc = frame_times(f, &kernel_ms[k], &resolve_ms[k]);
+        if (rc) return rc;
+    }
+    *n_out = n;
     return PT_OK;
 }
 
 int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     if (!S || !key) return fail(PT_ERR_INVALID_ARG, "null argument");
     const std::string k(key);
-    if (k == "blocks_per_cu") S->opt_blocks_per_cu = value;
+    if (k == "blocks_per_cu") {
+        if (value < 0 || value > 32) return fail(PT_ERR_INVALID_ARG, "blocks_per_cu must be 0 (automatic) .. 32");
+        S->opt_blocks_per_cu = value;
+    }
     else if (k == "scratch_bytes") S->opt_scratch_bytes = value;
     else if (k == "force_global") S->opt_force_global = value;
     else if (k == "stats") S->opt_stats = value;
@@ -1044,6 +1097,10 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "chunk") S->opt_chunk = value;
     else if (k == "item_order") S->opt_item_order = value;
     else if (k == "specialize") S->opt_specialize = value;
+    else if (k == "timing_frames") {
+        if (value < 1 || value > 4096) return fail(PT_ERR_INVALID_ARG, "timing_frames must be 1 .. 4096");
+        S->opt_timing_frames = value;
+    }
     else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
     else if (k == "v2_inner") S->opt_v2_inner = value;
@@ -1058,7 +1115,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     if (k == "grid") *value = S->info_grid;
     else if (k == "lds_bytes") *value = S->info_lds_bytes;
     else if (k == "lds_scene") *value = S->info_lds_scene;
-    else if (k == "residency") *value = scene_residency(S, which_tree(S, PT_TRAVERSAL_EXACT));
+    else if (k == "residency") *value = scene_residency(S, which_tree(S));
     else if (k == "passes") *value = S->info_passes;
     else if (k == "occupancy") *value = S->info_occupancy;                // what the occupancy query allows
     else if (k == "blocks_per_cu") *value = S->info_blocks_per_cu;        // what the last launch used
@@ -1072,16 +1129,16 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     }
     else if (k == "num_cus") *value = S->num_cus;
     else if (k == "bvh_depth") *value = S->tree[0].depth;
-    else if (k == "stack_entries") *value = S->tree[which_tree(S, PT_TRAVERSAL_EXACT)].stack_cap;   // per lane, sentinel included
+    else if (k == "stack_entries") *value = S->tree[which_tree(S)].stack_cap;   // per lane, sentinel included
     else if (k == "fast_tree") *value = S->have_fast ? 1 : 0;             // an internal tree exists (the caller's tree is nested)
     else if (k == "debug_reruns") *value = S->info_debug_reruns;          // rays the last pt_debug_intersect reran in reference order
     else if (k == "fast_tree_cost_permille") *value = S->fast_cost_permille;   // summed inner-box area, internal tree / caller's tree x 1000 (0: none built)
     else if (k == "fast_tree_is_callers") *value = (S->have_fast && S->fast_is_callers_topology) ? 1 : 0;
-    else if (k == "fast_tree_on") *value = which_tree(S, PT_TRAVERSAL_EXACT);    // ... and the next exact render traverses it
+    else if (k == "fast_tree_on") *value = which_tree(S);    // ... and the next exact render traverses it
     else if (k == "fast_tree_depth") *value = S->have_fast ? S->tree[1].depth : 0;
     else if (k == "scene_bytes") *value = S->scene_bytes;
     else if (k == "num_inner_nodes") *value = S->tree[0].num_nodes;
-    else if (k == "top_nodes") { const int w = which_tree(S, PT_TRAVERSAL_EXACT); *value = make_plan(S, scene_residency(S, w), false, w).top_count; }
+    else if (k == "top_nodes") { const int w = which_tree(S); *value = make_plan(S, scene_residency(S, w), false, w).top_count; }
     else if (k == "device") *value = S->device;
     else if (k.rfind("diag", 0) == 0 && k.size() >= 5 && k.size() <= 7 && k.find_first_not_of("0123456789", 4) == std::string::npos &&
              std::stoi(k.substr(4)) < 8 + kNumCounters - kTimelineBase) {
@@ -1103,7 +1160,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     }
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
-        const int w = which_tree(S, k == "vgprs_pruned" ? PT_TRAVERSAL_PRUNED : PT_TRAVERSAL_EXACT);
+        const int w = which_tree(S);
         TraceFn fn = pick_kernel(S, scene_residency(S, w), k == "vgprs_pruned", S->opt_stats != 0, w == 1);
         if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
@@ -1192,9 +1249,10 @@ int pt_debug_intersect(pt_scene* S, const float* rays, int n, int traversal, flo
     DevBuf<int32_t> dp, dn;
     int rc;
     if ((rc = dr.ensure((size_t)n * 8)) || (rc = dt.ensure((size_t)n * 3)) || (rc = dp.ensure(n)) || (rc = dn.ensure(1))) return rc;
-    // exact traversal: the internal tree with reference-order reruns when there is one (whatever the scene's size: this kernel
-    // reads nodes from global memory), so that the closest hits — ties included — can be checked ray by ray; else the caller's
-    const bool fast = S->have_fast && S->opt_fast_tree && traversal == PT_TRAVERSAL_EXACT;
+    // the tree renders traverse — exact and pruned alike (which_tree): the internal tree with ties settled in the caller's visit
+    // order and reference-order reruns when there is one (whatever the scene's size: this kernel reads nodes from global
+    // memory), so that the closest hits — ties included — can be checked ray by ray; else the caller's
+    const bool fast = S->have_fast && S->opt_fast_tree;
     select_tree(S, fast ? 1 : 0, fast);
     const int cap = fast && S->dev.redo_cap > S->dev.stack_cap ? S->dev.redo_cap : S->dev.stack_cap;
     const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)cap * 64u * 4u;

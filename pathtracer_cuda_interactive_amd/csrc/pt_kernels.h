@@ -632,11 +632,11 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
     r.tfar = rays[8 * k + 7];
     ptd::TravStats st;
     ptd::Hit h;
-    if (!PRUNE && scn.fallback) {                         // internal tree; the caller's for rays with a zero direction component
+    if (scn.fallback) {                                   // internal tree; the caller's for rays with a zero direction component
         ptd::SceneView sv_ref = sv;
         sv_ref.nodes = scn.ref_nodes; sv_ref.root_ref = scn.ref_root_ref; sv_ref.fixed_order = 0;
         bool rerun;
-        h = ptd::intersect_any_tree(sv, sv_ref, r, stk, rerun);
+        h = ptd::intersect_any_tree<PRUNE>(sv, sv_ref, r, stk, rerun);
         if (rerun) atomicAdd(reruns, 1);
     } else {
         h = ptd::intersect<PRUNE, false>(sv, r, stk, st);
@@ -669,7 +669,9 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(SceneDev scn, unsigned lo
     const float phi = 6.2831853f * ptm::pcg_float(rng);
     const float rr = __builtin_sqrtf(__builtin_fmaxf(0.0f, 1.0f - z * z));
     ptd::Ray r;
-    r.dir = ptm::mk(rr * __builtin_cosf(phi), rr * __builtin_sinf(phi), z);
+    float sn, cs;
+    ptm::sincos_det(phi, sn, cs);                        // own sin / cos: the same probe rays, hence the same choice of tree, on every ROCm build
+    r.dir = ptm::mk(rr * cs, rr * sn, z);
     const DPrim* pr = scn.prims + prim;
     const float4 a = ptd::ld4(pr, 0), b = ptd::ld4(pr, 1), c = ptd::ld4(pr, 2);
     if (__builtin_bit_cast(int32_t, c.y) < 0) {          // sphere: center + radius * dir

@@ -320,6 +320,8 @@ __device__ __forceinline__ Hit intersect(const SceneView& sv, const Ray& ray, in
 // the caller's visit order inside leaf_step (ref_visits_first), and a ray with a zero direction component is traced on the
 // caller's tree (`sv_ref`) instead (pt_api.hip: validate_and_build has the argument).  The trace kernel inlines the same three steps into its
 // scheduler; this run-to-completion form serves pt_debug_intersect.  `rerun` reports that the reference order was needed.
+// PRUNE: the opt-in pruned traversal takes the same tree and the same tie handling (launch_render), its reruns are exact.
+template <bool PRUNE = false>
 __device__ __forceinline__ Hit intersect_any_tree(const SceneView& sv, const SceneView& sv_ref, const Ray& ray, int32_t* stk, bool& rerun) {
     Trav t;
     TravStats st;
@@ -331,7 +333,7 @@ __device__ __forceinline__ Hit intersect_any_tree(const SceneView& sv, const Sce
         t.cur = kDone;
     }
     while (t.cur != kDone) {
-        while (t.cur >= 0) inner_step<false, false, int32_t>(sv, ray.org, t, stk);
+        while (t.cur >= 0) inner_step<PRUNE, false, int32_t>(sv, ray.org, t, stk);
         if (t.cur != kDone) leaf_step<int32_t, false>(sv, ray, t, stk, false, true);
     }
     rerun = t.redo;

@@ -16,6 +16,8 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -48,20 +50,34 @@ inline double sbox_area(const SBox& b) {
 
 // Runs the jobs 1 .. count-1 on threads of their own and job 0 on the caller's; a thread that cannot be started (process or
 // thread limits of the host) simply means its job runs on the caller's thread as well.  Jobs must be independent.
+// An exception thrown by any job (std::bad_alloc in a sort key array, say) is caught on its thread, every thread is joined,
+// and the first one caught is rethrown on the caller's thread — never std::terminate.
 template <class F>
 inline void run_side_by_side(int count, F&& job) {
     std::vector<std::thread> side;
     std::vector<int> inline_jobs;
+    std::vector<std::exception_ptr> failed((size_t)(count > 0 ? count : 1));
+    auto guarded = [&job, &failed](int k) {
+        try {
+            job(k);
+        } catch (...) {
+            failed[(size_t)k] = std::current_exception();
+        }
+    };
     for (int k = 1; k < count; k++) {
         try {
-            side.emplace_back([&job, k]() { job(k); });
+            side.emplace_back(guarded, k);
         } catch (const std::system_error&) {
+            inline_jobs.push_back(k);
+        } catch (const std::bad_alloc&) {
             inline_jobs.push_back(k);
         }
     }
-    job(0);
-    for (int k : inline_jobs) job(k);
+    guarded(0);
+    for (int k : inline_jobs) guarded(k);
     for (std::thread& t : side) t.join();
+    for (const std::exception_ptr& e : failed)
+        if (e) std::rethrow_exception(e);
 }
 
 // leaf_boxes: n x {lo.xyz, hi.xyz}, all finite.  out: the reference's node pool layout (bvh.cuh:7-15), 2n-1 nodes in

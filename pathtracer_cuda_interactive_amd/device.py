@@ -16,7 +16,7 @@ _lib = None
 EXPORTS = [
     "pt_api_version", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_async",
     "pt_render_accumulate", "pt_get_counters", "pt_scene_set_option", "pt_scene_get_info", "pt_debug_math",
-    "pt_debug_intersect", "pt_debug_math_host", "pt_bvh_build_device", "pt_bvh_build_sweep",
+    "pt_debug_intersect", "pt_debug_math_host", "pt_bvh_build_device", "pt_bvh_build_sweep", "pt_get_frame_times",
 ]
 
 
@@ -38,6 +38,7 @@ def lib():
         L.pt_render_async.argtypes = [vp, C.POINTER(PtRenderParams), vp, vp]
         L.pt_render_accumulate.argtypes = [vp, C.POINTER(PtRenderParams), vp, vp]
         L.pt_get_counters.argtypes = [vp, C.POINTER(PtCounters)]
+        L.pt_get_frame_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.pt_scene_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.pt_scene_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
         L.pt_debug_math.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
@@ -108,6 +109,14 @@ class DeviceScene:
         c = PtCounters()
         _check(lib().pt_get_counters(self._h, C.byref(c)))
         return c
+
+    def frame_times(self, max_frames):
+        """(kernel_ms[], resolve_ms[]) of the last render calls, oldest first (option "timing_frames" sets how many are kept)."""
+        k = (C.c_double * max(max_frames, 1))()
+        r = (C.c_double * max(max_frames, 1))()
+        n = C.c_int()
+        _check(lib().pt_get_frame_times(self._h, int(max_frames), k, r, C.byref(n)))
+        return np.array(k[: n.value]), np.array(r[: n.value])
 
     def intersect(self, rays, traversal=PT_TRAVERSAL_DEFAULT):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

@@ -34,12 +34,13 @@ def assemble(parts, height, width, world):
     return out
 
 
-def render_sharded(render_rows, params, rank=None, world=None, group=None, dst=0):
+def render_sharded(render_rows, params, rank=None, world=None, group=None, dst=0, force_collective=False):
     """Render one frame across the process group.
 
     render_rows(q) -> tensor [rows_of(rank), W, 3] (float32) for the shard params q; on the GPU path it
     wraps DeviceScene.render_into on the current stream, in the CPU tests it wraps the oracle.
-    Returns the assembled frame on rank `dst`, None elsewhere.  world == 1 needs no process group.
+    Returns the assembled frame on rank `dst`, None elsewhere.  world == 1 needs no process group — unless
+    force_collective asks for the gather + de-interleave all the same (a one-rank group: what that step costs, measured).
     """
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -48,7 +49,7 @@ def render_sharded(render_rows, params, rank=None, world=None, group=None, dst=0
     H, W = int(params.height), int(params.width)
     q = shard_params(params, rank, world)
     mine = render_rows(q)
-    if world == 1:
+    if world == 1 and not force_collective:
         return mine
     max_rows = rows_of(0, world, H)
     if mine.shape[0] != max_rows:                      # ragged tail: pad so every rank sends the same size
@@ -85,8 +86,8 @@ class ShardedRenderer:
             self.scene.render_into(q, self._band.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return self._band
 
-    def render(self, params, rank=None, world=None, group=None):
-        return render_sharded(self.render_rows, params, rank, world, group)
+    def render(self, params, rank=None, world=None, group=None, force_collective=False):
+        return render_sharded(self.render_rows, params, rank, world, group, force_collective=force_collective)
 
     def close(self):
         self.scene.close()

@@ -313,3 +313,31 @@ def test_full_size_frames_are_the_same_on_both_trees(name, w, h, spp):
     assert_bit_equal(a, b, f"{name} {w}x{h}x{spp}: internal tree vs caller's tree")
     if name in ("cbox", "buddha_standin", "dragon_standin"):
         assert reruns > 0            # rays with a zero direction component did occur in this frame
+
+
+@pytest.mark.gpu
+def test_more_blocks_per_cu_than_any_default_keeps_the_rerun_stacks_inside_their_buffer(oracle):
+    """`blocks_per_cu` is a caller's option; the reference-order reruns (rays with a zero direction component: cbox has ~20 per
+    million segments) index a global-memory stack by blockIdx.  The buffer is sized from the grid that is launched, so a grid
+    of 12 blocks per CU renders the same bits as the default one — and an option beyond the documented range is refused."""
+    from pathtracer_cuda_interactive_amd import PtError
+    hs, d = load_scene("cbox")
+    p = hs.render_params(640, 480, 8)
+    want, cnt = oracle.render(d, p)
+    ds = dev.DeviceScene(d)
+    try:
+        assert ds.info("fast_tree_on") == 1
+        ds.set_option("stats", 1)
+        for bpc in (0, 12, 2):
+            ds.set_option("blocks_per_cu", bpc)
+            img = ds.render(p)
+            assert_bit_equal(img, want, f"cbox blocks_per_cu={bpc}")
+            if bpc:
+                assert ds.info("blocks_per_cu") == bpc and ds.info("grid") == bpc * ds.info("num_cus")
+            assert ds.info("redo_segments") > 0          # the reruns did happen
+        with pytest.raises(PtError):
+            ds.set_option("blocks_per_cu", 33)
+        with pytest.raises(PtError):
+            ds.set_option("blocks_per_cu", -1)
+    finally:
+        ds.close()

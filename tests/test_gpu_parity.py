@@ -506,3 +506,31 @@ def test_scene_handles_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 60 create/destroy cycles"
+
+
+@pytest.mark.gpu
+def test_frame_times_of_frames_enqueued_without_a_host_sync(oracle):
+    """pt_get_frame_times: the library keeps the HIP events of the last `timing_frames` render calls, so a caller may enqueue
+    frame after frame on a stream (bench.py's timed loop) and read every frame's kernel time afterwards."""
+    import torch
+    hs, d = load_scene("cbox")
+    p = hs.render_params(160, 120, 4)
+    want, _ = oracle.render(d, p)
+    ds = dev.DeviceScene(d)
+    try:
+        ds.set_option("timing_frames", 5)
+        out = torch.empty((120, 160, 3), dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(7):
+            ds.render_into(p, out.data_ptr(), stream)
+        k, r = ds.frame_times(16)
+        assert len(k) == 5 and len(r) == 5 and (k > 0).all() and (r > 0).all()
+        k2, _ = ds.frame_times(2)
+        assert len(k2) == 2 and np.array_equal(k2, k[-2:])
+        c = ds.counters()
+        assert c.kernel_ms == k[-1]
+        assert_bit_equal(out.cpu().numpy(), want, "last of seven frames enqueued back to back")
+        with pytest.raises(PtError):
+            ds.set_option("timing_frames", 0)
+    finally:
+        ds.close()

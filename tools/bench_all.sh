@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box: the full GPU test suite, then bench.py on all five BASELINE configs (exact traversal, with the
 # cpu_baseline leg), the pruned bunny line and the progressive (interactive-shape) lines.  -> gpurun_out/<tag>_*
-TAG=${1:-r02}
+TAG=${1:-r03}
 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${TAG}_pytest_gpu.log
 for S in cbox bunny scene1 buddha_standin dragon_standin; do
   python3 bench.py --scene $S > gpurun_out/${TAG}_bench_$S.json 2> gpurun_out/${TAG}_bench_$S.err || echo "bench $S failed"
-  python3 -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_bench_$S.json')); print('$S', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['physical'], d.get('cpu_baseline',{}).get('value'))"
+  python3 -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_bench_$S.json')); print('$S', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline'].get('physical_bound'), d['roofline'].get('physical_frac'), d.get('cpu_baseline',{}).get('value'), d.get('parity_rows'))"
 done
 python3 bench.py --scene bunny --traversal pruned --no-cpu-baseline > gpurun_out/${TAG}_bench_bunny_pruned.json 2>/dev/null
 # the same configs on the caller's (reference median-split) tree instead of the library's internal one: same images, more node visits

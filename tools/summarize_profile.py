@@ -65,6 +65,8 @@ def main(tag, scene, traversal):
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0                 # summed over the 8 XCDs
         d["kernel_cycles"] = cycles
         d["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles)    # wave64 VALU = 2 cycles on a SIMD-32, 1024 SIMDs
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "kernel_cycles" in d:
+        d["l1_tag_lookups_per_cycle_per_cu"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / d["kernel_cycles"] / 256.0
     if "SQ_WAVE_CYCLES" in c:
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if k in c:
