@@ -42,6 +42,11 @@ typedef struct {                                                          /* int
 typedef pt_oracle_counters o_counters;
 #define O_TRACE(c, ch) do { if ((c)->trace && (c)->trace_len < (c)->trace_cap) (c)->trace[(c)->trace_len++] = (ch); } while (0)
 
+/* TEST HOOK (tests/test_reference_images.py): deliberately WRONG variants of the estimator, to show that the pin on the
+ * reference's screenshots can fail.  0 = the reference's algorithm; never set outside that test. */
+static int g_oracle_mutation = 0;
+int pt_oracle_set_mutation(int bits) { int old = g_oracle_mutation; g_oracle_mutation = bits; return old; }
+
 #define ORACLE_LIBM 0
 #define NS det
 #include "pt_oracle_core.inc"

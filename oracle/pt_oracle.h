@@ -80,6 +80,17 @@ int pt_oracle_intersect(const pt_scene_desc* scene, const float* rays, int n, in
 int pt_oracle_intersect_work(const pt_scene_desc* scene, const float* rays, int n, int math_mode, uint32_t* out_inner,
                              uint32_t* out_leaf, uint64_t* out_leaf_set);
 
+/* TEST HOOK: mutations of the estimator (bit mask; 0 = none = the reference's algorithm).  Used only to demonstrate that the
+ * statistical pin on the reference's screenshots fails for a wrong estimator (tests/test_reference_images.py).  Process-wide,
+ * not thread-safe against a running render.  Returns the previous mask.
+ *   DIFFUSE_NO_INV_PI  eval_brdf's diffuse value without the 1/pi (scene.h:370-375), pdf unchanged
+ *   RR_NO_WEIGHT       Russian-roulette survivors keep their throughput (radiance.cuh:68-74 without the division)
+ *   SCHLICK_POW4       (1 - cos)^4 instead of ^5 in schlick_fresnel (scene.h:333-336)
+ *   RR_FLOOR_QUARTER   CONTROL: roulette floor 0.25 instead of 0.5 — another estimator with the SAME expectation */
+enum { PT_ORACLE_MUT_DIFFUSE_NO_INV_PI = 1, PT_ORACLE_MUT_RR_NO_WEIGHT = 2, PT_ORACLE_MUT_SCHLICK_POW4 = 4,
+       PT_ORACLE_MUT_RR_FLOOR_QUARTER = 8 };
+int pt_oracle_set_mutation(int bits);
+
 /* math KATs: op 0 sincos(x)->(out0=sin,out1=cos); op 1 powf(x,y)->out0; math_mode as above */
 int pt_oracle_math(int op, int math_mode, const float* x, const float* y, float* out0, float* out1, int n);
 /* n_draws uint32 + float outputs of init_pcg32(stream, seed); also returns state/inc after init */

@@ -19,6 +19,7 @@
 #include "pt_internal.h"
 #include "pt_tree_sweep.h"
 #include "pt_kernels.h"
+#include "pt_kernel_q.h"
 
 using namespace ptl;
 using namespace ptk;
@@ -160,10 +161,12 @@ struct pt_scene {
     int64_t opt_lds_budget_kb = 0;   // scenes in global memory: LDS per block for traversal stacks + top-of-tree cache (0 = 26 KB: 6 blocks per CU)
     int64_t opt_item_order = 1;      // work item order inside a band: 1 = row-major (all samples of a row, then the next row), 0 = sample-major
     int64_t opt_xcd_regions = 0;     // 0 = 8 row bands (one per XCD); 1 = a single work queue
-    int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel
+    int64_t opt_kernel = 2;          // 2 = decoupled traversal/shading (default), 1 = segment-synchronous wavefront kernel,
+                                     // 3 = paths regrouped across the waves of a workgroup (pt_kernel_q.h; LDS-resident scenes, else as 2)
+    int64_t opt_q_target = 0, opt_q_swap = 0, opt_q_low = 0;   // schedule knobs of kernel 3; 0 = automatic
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
     // info of last launch
-    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0, info_debug_reruns = 0, fast_cost_permille = 0;
+    int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0, info_debug_reruns = 0, fast_cost_permille = 0, info_kernel = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
     // HIP events of the last `opt_timing_frames` render calls (a ring; default 1): a caller that enqueues frame after frame
     // without a host sync in between — bench.py's timed loop — reads every frame's kernel time afterwards (pt_get_frame_times)
@@ -697,24 +700,58 @@ TraceFn pick_kernel_nee(int res, bool stats, int spec) {
     return pick_nee_r<0, 32, 4>(stats, spec);
 }
 
+// trace_kernel_q (option "kernel" = 3): LDS-resident scenes, exact traversal, no next-event estimation.
+using TraceFnQ = void (*)(SceneDev, RenderDev, LdsPlan, QParams, float4*, uint32_t*, unsigned long long*);
+template <int RES>
+TraceFnQ pick_q_r(bool stats, int spec) {
+    if (spec == 2) return stats ? trace_kernel_q<RES, true, 2> : trace_kernel_q<RES, false, 2>;
+    if (spec == 1) return stats ? trace_kernel_q<RES, true, 1> : trace_kernel_q<RES, false, 1>;
+    return stats ? trace_kernel_q<RES, true, 0> : trace_kernel_q<RES, false, 0>;
+}
+TraceFnQ pick_kernel_q(const pt_scene* S, int res) {
+    const int spec = !(S->tri_only && S->opt_specialize) ? 0 : (S->diffuse_only ? 2 : 1);
+    return res == 2 ? pick_q_r<2>(S->opt_stats != 0, spec) : pick_q_r<1>(S->opt_stats != 0, spec);
+}
+
+// LDS plan of trace_kernel_q: the staged scene as for v2, 16-bit traversal stacks for the kQT traversal waves only, then the
+// control words and the two rings (contiguous: the kernel clears them in one sweep).  Also settles the schedule knobs.
+QParams make_plan_q(const pt_scene* S, LdsPlan& lp, int which) {
+    QParams q{};
+    uint32_t off = lp.stack_off + (uint32_t)kQT * (uint32_t)S->tree[which].stack_cap * 64u * 2u;
+    off = align16(off);
+    q.ctl_off = off; off += kQCtlBytes;
+    q.shade_off = off; off += kQRing * kQEntryBytes;
+    q.ready_off = off; off += kQRing * kQEntryBytes;
+    lp.total = align16(off);
+    // Paths in flight per workgroup.  The bound that keeps the rings from filling up for good (pt_kernel_q.h): with every
+    // T-lane holding a finished path, a ring that cannot take a wave's worth more (> ring - 64 entries each) — that many
+    // paths must not exist:  target <= T-lanes + 2 x ring - 128.
+    const int32_t t_lanes = kQT * 64, cap = t_lanes + 2 * (int32_t)kQRing - 128;
+    int32_t target = S->opt_q_target > 0 ? (int32_t)S->opt_q_target : t_lanes + (int32_t)kQRing;
+    q.target = std::max(64, std::min(target, cap));
+    q.swap = S->opt_q_swap > 0 ? (int32_t)std::min<int64_t>(S->opt_q_swap, 64) : 16;
+    q.low = S->opt_q_low > 0 ? (int32_t)S->opt_q_low : 8;
+    return q;
+}
+
 // Residency the next launch will use (see make_plan).
 // The tree a render traverses: the internal tree on the default kernel where scene creation kept one (see launch_render), the
 // caller's tree otherwise.  Pruned traversal (opt-in, tolerance semantics: DESIGN.md §6) takes the internal tree as well — left
 // child first like the exact one, so that its short stacks hold; bunny 7.55 -> 3.89 ms, no pixel moved.
 int which_tree(const pt_scene* S) {
-    return (S->have_fast && S->opt_fast_tree && S->opt_kernel == 2) ? 1 : 0;
+    return (S->have_fast && S->opt_fast_tree && S->opt_kernel >= 2) ? 1 : 0;
 }
 
 int scene_residency(const pt_scene* S, int which = 0) {
     const pt_scene::Tree& T = S->tree[which];
     if (S->opt_force_global || S->scene_bytes > kLdsSceneLimit)
-        return (T.top_avail > 0 && S->opt_top_cache && S->opt_kernel == 2 && !S->opt_force_global) ? 3 : 0;
-    if (S->opt_kernel == 2 && S->opt_octants && T.have_oct) return 2;
+        return (T.top_avail > 0 && S->opt_top_cache && S->opt_kernel >= 2 && !S->opt_force_global) ? 3 : 0;
+    if (S->opt_kernel >= 2 && S->opt_octants && T.have_oct) return 2;
     return 1;
 }
 
 TraceFn pick_kernel(const pt_scene* S, int res, bool prune, bool stats, bool internal_tree) {
-    if (S->opt_kernel == 2) {
+    if (S->opt_kernel >= 2) {
         int t = (int)S->opt_v2_thresh, i = (int)S->opt_v2_inner, w = (int)S->opt_v2_minw;
         const bool lds = res == 1 || res == 2;
         if (t == 0) t = lds ? 40 : 32;
@@ -746,8 +783,8 @@ int read_slot_sums(const pt_scene* S, unsigned long long* out) {
 }
 
 // Blocks of a trace launch: every resident slot of the device, or fewer when there is not enough work to fill them.
-int launch_grid(int num_cus, int blocks_per_cu, uint64_t work_items) {
-    const uint64_t blocks_needed = (work_items + kBlock - 1) / kBlock;
+int launch_grid(int num_cus, int blocks_per_cu, uint64_t work_items, int block_threads = kBlock) {
+    const uint64_t blocks_needed = (work_items + (uint64_t)block_threads - 1) / (uint64_t)block_threads;
     return (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)num_cus * (uint64_t)blocks_per_cu, blocks_needed));
 }
 // Lanes (= global-memory stack columns of the reference-order reruns) of that launch.
@@ -838,21 +875,35 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     const int which = which_tree(S);
     const int res = scene_residency(S, which);
     const bool lds_scene = res == 1 || res == 2;
-    const LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel == 2, which);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
+    LdsPlan lp = make_plan(S, res, lds_scene && S->opt_kernel >= 2, which);   // trace_kernel_v2 keeps 16-bit stacks for LDS scenes
     if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
     if (p->flags & ~PT_RENDER_NEE) return fail(PT_ERR_INVALID_ARG, "unknown bits in pt_render_params.flags");
     const bool nee = (p->flags & PT_RENDER_NEE) != 0;
-    if (nee && (S->opt_kernel != 2 || traversal != PT_TRAVERSAL_EXACT))
+    if (nee && (S->opt_kernel < 2 || traversal != PT_TRAVERSAL_EXACT))
         return fail(PT_ERR_UNSUPPORTED, "PT_RENDER_NEE runs on the default kernel with exact traversal only");
-    TraceFn fn = nee ? pick_kernel_nee(res, S->opt_stats != 0, (S->tri_only && S->diffuse_only && S->opt_specialize) ? 2 : 0)
-                     : pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0, which == 1);
-    if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
-    if (S->cfg_fn != reinterpret_cast<const void*>(fn) || S->cfg_lds != lp.total) {
+    // kernel 3 (paths regrouped across the waves of a workgroup) serves LDS-resident scenes with exact traversal; everything
+    // else runs on kernel 2
+    const bool use_q = S->opt_kernel == 3 && lds_scene && !nee && traversal == PT_TRAVERSAL_EXACT;
+    QParams qp{};
+    TraceFnQ fnq = nullptr;
+    TraceFn fn = nullptr;
+    if (use_q) {
+        qp = make_plan_q(S, lp, which);
+        if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
+        fnq = pick_kernel_q(S, res);
+    } else {
+        fn = nee ? pick_kernel_nee(res, S->opt_stats != 0, (S->tri_only && S->diffuse_only && S->opt_specialize) ? 2 : 0)
+                 : pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0, which == 1);
+        if (!fn) return fail(PT_ERR_INVALID_ARG, "no kernel variant compiled for these v2_thresh / v2_inner options");
+    }
+    const void* fn_any = use_q ? reinterpret_cast<const void*>(fnq) : reinterpret_cast<const void*>(fn);
+    const int block_threads = use_q ? kQBlock : kBlock;
+    if (S->cfg_fn != fn_any || S->cfg_lds != lp.total) {
         if (lp.total > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
+            HIP_TRY(hipFuncSetAttribute(fn_any, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.total));
         int q = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(fn), kBlock, lp.total));
-        S->cfg_fn = reinterpret_cast<const void*>(fn); S->cfg_lds = lp.total; S->cfg_occ = std::max(q, 1);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn_any, block_threads, lp.total));
+        S->cfg_fn = fn_any; S->cfg_lds = lp.total; S->cfg_occ = std::max(q, 1);
     }
     const int occ = S->cfg_occ;
     // scenes read from global memory: 6 blocks per CU (what 80 VGPRs allow) with a 26 KB stack + top-of-tree budget each.
@@ -860,6 +911,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     // worth having: bunny +0.6 %, buddha stand-in -1.1 %, dragon stand-in -7.6 % against 5 blocks of 31 KB
     // (profiles/r02_tune_round41_lds_budget.log, r02_tune_round42_blocks.log).  LDS-resident scenes take every block they can get.
     int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (!lds_scene ? std::min(occ, 6) : occ);
+    S->info_kernel = use_q ? 3 : S->opt_kernel == 1 ? 1 : 2;
     S->info_occupancy = occ;
     S->info_blocks_per_cu = bpc;
     S->info_lds_bytes = lp.total;
@@ -869,7 +921,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         // one global-memory stack column per lane of the LARGEST grid this call launches (pass 0 traces the most samples) for
         // the reruns (rare: latency does not matter).  Sized from the grid, not from an assumed blocks-per-CU: `blocks_per_cu`
         // is a caller's option and the kernel indexes the buffer by blockIdx (pt_kernels.h: redo_stk).
-        const size_t lanes = redo_stack_lanes(S->num_cus, bpc, npix * spp_pass);
+        const size_t lanes = use_q ? (size_t)launch_grid(S->num_cus, bpc, npix * spp_pass, kQBlock) * kQS * 64    // S-waves rerun
+                                   : redo_stack_lanes(S->num_cus, bpc, npix * spp_pass);
         if ((rc = S->redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
     }
     select_tree(S, which, which == 1);
@@ -904,8 +957,8 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
             rd.div_npix_last = make_fastdiv((uint32_t)std::max(rest, 1) * (uint32_t)p->width);
         }
 
-        const int grid = launch_grid(S->num_cus, bpc, rd.total_work);
-        if (which == 1 && (size_t)grid * kBlock * (size_t)S->tree[0].stack_cap > S->redo_stack.n)
+        const int grid = launch_grid(S->num_cus, bpc, rd.total_work, block_threads);
+        if (which == 1 && (size_t)grid * (use_q ? kQS * 64 : kBlock) * (size_t)S->tree[0].stack_cap > S->redo_stack.n)
             return fail(PT_ERR_DEVICE, "internal error: rerun stacks smaller than the grid");
         S->info_grid = grid;
         // chunk: work items a wave reserves per atomic.  Big launches (a wave traces >= 2048 items): 128 — the waves of a
@@ -913,7 +966,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         // buys nothing more and saturates the counters on cheap scenes: profiles/r02_tune_round36_*.log); mid-size
         // launches 256; small launches (interactive 1-2 spp frames) down to 64 so that the items are spread over all
         // resident waves instead of the first total/256 of them
-        const uint64_t per_wave = rd.total_work / ((uint64_t)grid * (kBlock / 64));
+        const uint64_t per_wave = rd.total_work / ((uint64_t)grid * (use_q ? kQS : kBlock / 64));     // waves that draw from the feed
         rd.chunk = per_wave >= 2048 ? 128u
                  : per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
         if (S->opt_chunk > 0) rd.chunk = (uint32_t)std::min<int64_t>(kMaxChunk, std::max<int64_t>(64, (S->opt_chunk / 64) * 64));
@@ -929,8 +982,12 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         const pt_scene::PassEvents pe = frec.ev[pass];
         if (pass > 0) HIP_TRY(hipMemsetAsync(S->ctl.p, 0, kWorkBytes, stream));
         HIP_TRY(hipEventRecord(pe.t0, stream));
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
-                           S->work_counter(), S->counters());
+        if (use_q)
+            hipLaunchKernelGGL(fnq, dim3(grid), dim3(kQBlock), lp.total, stream, S->dev, rd, lp, qp, S->samples.p,
+                               S->work_counter(), S->counters());
+        else
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
+                               S->work_counter(), S->counters());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(pe.t1, stream));
 
@@ -956,6 +1013,16 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     }
     S->have_timing = true;
     return PT_OK;
+}
+
+// trace_kernel_q bounds every wait on its rings; a wait that ran into its bound leaves a mark in counter slot 15 and an
+// invalid frame behind.  (The stream has been synchronised.)
+int check_schedule_error(const pt_scene* S) {
+    if (S->info_kernel != 3 || !S->ctl.p) return PT_OK;
+    unsigned long long c[kSlotStride];
+    int rc = read_slot_sums(S, c);
+    if (rc) return rc;
+    return c[15] ? fail(PT_ERR_DEVICE, "trace_kernel_q: a wait on a ring ran into its bound (schedule error, frame invalid)") : PT_OK;
 }
 
 // HIP-event times of one recorded render call, summed over its sample passes (the events must have completed).
@@ -1028,7 +1095,7 @@ int pt_render(pt_scene* S, const pt_render_params* p, float* fb, int fb_on_devic
         int rc = launch_render(S, p, fb, 0, nullptr);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(nullptr));
-        return PT_OK;
+        return check_schedule_error(S);
     }
     RowSel rows;
     int rc = select_rows(p, &rows);
@@ -1041,7 +1108,7 @@ int pt_render(pt_scene* S, const pt_render_params* p, float* fb, int fb_on_devic
     rc = launch_render(S, p, S->fb_tmp.p, 0, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(fb, S->fb_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost));
-    return PT_OK;
+    return check_schedule_error(S);
 }
 
 int pt_get_counters(pt_scene* S, pt_counters* out) {
@@ -1055,6 +1122,7 @@ int pt_get_counters(pt_scene* S, pt_counters* out) {
     int rc = read_slot_sums(S, c);
     if (rc) return rc;
     out->paths = c[0]; out->segments = c[1]; out->node_visits = c[2]; out->leaf_tests = c[3];
+    if (S->info_kernel == 3 && c[15]) return fail(PT_ERR_DEVICE, "trace_kernel_q: a wait on a ring ran into its bound (schedule error, frame invalid)");
     if (S->have_timing && S->last_frame()) {
         int rc2 = frame_times(*S->last_frame(), &out->kernel_ms, &out->resolve_ms);
         if (rc2) return rc2;
@@ -1101,7 +1169,10 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
         if (value < 1 || value > 4096) return fail(PT_ERR_INVALID_ARG, "timing_frames must be 1 .. 4096");
         S->opt_timing_frames = value;
     }
-    else if (k == "kernel") { if (value != 1 && value != 2) return fail(PT_ERR_INVALID_ARG, "kernel must be 1 or 2"); S->opt_kernel = value; }
+    else if (k == "kernel") { if (value < 1 || value > 3) return fail(PT_ERR_INVALID_ARG, "kernel must be 1, 2 or 3"); S->opt_kernel = value; }
+    else if (k == "q_target") S->opt_q_target = value;
+    else if (k == "q_swap") S->opt_q_swap = value;
+    else if (k == "q_low") S->opt_q_low = value;
     else if (k == "v2_thresh") S->opt_v2_thresh = value;
     else if (k == "v2_inner") S->opt_v2_inner = value;
     else if (k == "v2_minw") S->opt_v2_minw = value;
@@ -1140,6 +1211,18 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "num_inner_nodes") *value = S->tree[0].num_nodes;
     else if (k == "top_nodes") { const int w = which_tree(S); *value = make_plan(S, scene_residency(S, w), false, w).top_count; }
     else if (k == "device") *value = S->device;
+    else if (k == "kernel") *value = S->info_kernel;                      // the kernel the last render ran on (1, 2 or 3)
+    else if (k == "block_threads") *value = S->info_kernel == 3 ? kQBlock : kBlock;
+    else if (k.rfind("qdiag", 0) == 0 && k.size() >= 6 && k.size() <= 7 && k.find_first_not_of("0123456789", 5) == std::string::npos &&
+             std::stoi(k.substr(5)) < 11) {
+        // schedule diagnostics of the last STATS render of trace_kernel_q: counter slots [4..14], see pt_kernel_q.h
+        DeviceGuard guard;
+        { int grc = guard.enter(S->device); if (grc) return grc; }
+        HIP_TRY(hipStreamSynchronize(S->last_stream));
+        unsigned long long c[kSlotStride] = {0};
+        if (S->ctl.p) { int rc = read_slot_sums(S, c); if (rc) return rc; }
+        *value = (int64_t)c[4 + std::stoi(k.substr(5))];
+    }
     else if (k.rfind("diag", 0) == 0 && k.size() >= 5 && k.size() <= 7 && k.find_first_not_of("0123456789", 4) == std::string::npos &&
              std::stoi(k.substr(4)) < 8 + kNumCounters - kTimelineBase) {
         // schedule diagnostics / launch timeline of the last STATS render (trace_kernel_v2): see pt_kernels.h
@@ -1161,9 +1244,16 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "vgprs" || k == "vgprs_pruned") {
         hipFuncAttributes fa;
         const int w = which_tree(S);
-        TraceFn fn = pick_kernel(S, scene_residency(S, w), k == "vgprs_pruned", S->opt_stats != 0, w == 1);
-        if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
+        const int res = scene_residency(S, w);
+        const void* f;
+        if (S->opt_kernel == 3 && (res == 1 || res == 2) && k == "vgprs") {
+            f = reinterpret_cast<const void*>(pick_kernel_q(S, res));
+        } else {
+            TraceFn fn = pick_kernel(S, res, k == "vgprs_pruned", S->opt_stats != 0, w == 1);
+            if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");
+            f = reinterpret_cast<const void*>(fn);
+        }
+        HIP_TRY(hipFuncGetAttributes(&fa, f));
         *value = fa.numRegs;
     } else return fail(PT_ERR_INVALID_ARG, "unknown info key " + k);
     return PT_OK;
