@@ -262,6 +262,10 @@ def main():
     ap.add_argument("--tree", default="internal", choices=["internal", "caller"],
                     help="exact traversal: the library's internal tree over the caller's leaf boxes (default; bit-identical "
                          "results) or the caller's (reference median-split) tree itself")
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="trace kernel: 0 = the library's default, 2 = decoupled traversal / shading per wave, 3 = paths regrouped across "
+                         "the waves of a workgroup (LDS-resident scenes), 1 = segment-synchronous")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="pt_scene_set_option before rendering (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-work-frames", action="store_true",
                     help="skip the two untimed counting frames behind config.work (profiling runs: only the timed kernel on the GPU)")
@@ -298,6 +302,7 @@ def main():
     force_gather = bool(args.force_gather) and world == 1
     if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")       # no RCCL version banner on stdout: rank 0 prints ONE JSON line there
         if force_gather and "MASTER_PORT" not in os.environ:
             import socket
             with socket.socket() as sock:
@@ -330,6 +335,11 @@ def main():
     R = StubRenderer(desc, hs) if stub else D.ShardedRenderer(desc)
     if not stub and args.tree == "caller":
         R.scene.set_option("fast_tree", 0)
+    if not stub and args.kernel:
+        R.scene.set_option("kernel", args.kernel)
+    for kv in ([] if stub else args.set):
+        k, v = kv.split("=")
+        R.scene.set_option(k, int(v))
     # The timed loop enqueues frame after frame on the stream (N>1: each followed by the gather) with NO host sync inside: the
     # library keeps the HIP events of the last `steps` render calls (option "timing_frames"), read after the closing fence.
     # Every frame renders the same streams, so its work counters are the last frame's.
@@ -425,7 +435,7 @@ def main():
                     "inner_visits_per_segment": work.get("inner_visits_per_segment") if work else None,
                     "callers_tree_inner_visits_per_segment": work.get("callers_tree_inner_visits_per_segment") if work else None,
                     "leaf_tests_per_segment": work.get("leaf_tests_per_segment") if work else None,
-                    "kernel": "trace_kernel_v2", "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                    "kernel": {1: "trace_kernel", 2: "trace_kernel_v2", 3: "trace_kernel_q"}.get(0 if stub else int(R.scene.info("kernel")), "stub"), "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                     "kernel_launches_per_step": passes,
                     "algorithmic_bytes_per_segment": wl["bytes_per_segment"], "segments_per_launch": int(seg_launch),
                     "note": ("scene staged in LDS (%d B): physical bound = VALU lane throughput, DESIGN.md 7" % R.scene.info("scene_bytes")) if lds_scene else

@@ -1022,7 +1022,7 @@ int check_schedule_error(const pt_scene* S) {
     unsigned long long c[kSlotStride];
     int rc = read_slot_sums(S, c);
     if (rc) return rc;
-    return c[15] ? fail(PT_ERR_DEVICE, "trace_kernel_q: a wait on a ring ran into its bound (schedule error, frame invalid)") : PT_OK;
+    return c[15] ? fail(PT_ERR_DEVICE, "trace_kernel_q: schedule error, frame invalid (bits " + std::to_string(c[15]) + ": 1 bounded wait ran out, 2 ring entry corrupted, 4 impossible path state)") : PT_OK;
 }
 
 // HIP-event times of one recorded render call, summed over its sample passes (the events must have completed).
@@ -1122,7 +1122,7 @@ int pt_get_counters(pt_scene* S, pt_counters* out) {
     int rc = read_slot_sums(S, c);
     if (rc) return rc;
     out->paths = c[0]; out->segments = c[1]; out->node_visits = c[2]; out->leaf_tests = c[3];
-    if (S->info_kernel == 3 && c[15]) return fail(PT_ERR_DEVICE, "trace_kernel_q: a wait on a ring ran into its bound (schedule error, frame invalid)");
+    if (S->info_kernel == 3 && c[15]) return fail(PT_ERR_DEVICE, "trace_kernel_q: schedule error, frame invalid (bits " + std::to_string(c[15]) + ": 1 bounded wait ran out, 2 ring entry corrupted, 4 impossible path state)");
     if (S->have_timing && S->last_frame()) {
         int rc2 = frame_times(*S->last_frame(), &out->kernel_ms, &out->resolve_ms);
         if (rc2) return rc2;

@@ -17,9 +17,10 @@
 // step never changes what is computed for a path: the frame is bit-identical to trace_kernel_v2's and the oracle's
 // (tests/test_gpu_parity.py::test_scheduler_variants_are_bit_identical, test_gpu_fullsize.py).
 //
-// Rings: 32-bit head / tail cursors claimed with compare-and-swap by one lane per wave, one flag word per entry
-// (0 empty, 1 full) so that a consumer never reads an entry before its producer has written it and a producer never
-// overwrites one that is still being read.  Every wait is bounded (kQSpinLimit / the wall-clock watchdog): a logic error
+// Rings: 32-bit head / tail cursors claimed with compare-and-swap by one lane per wave.  A position may be CLAIMED by a
+// consumer as soon as a producer has RESERVED it, and reserved again (one lap later) as soon as it has been claimed — so
+// every entry carries a sequence word that orders the four parties of two consecutive laps:  2 x lap = free for that
+// lap's producer, 2 x lap + 1 = written, 2 x lap + 2 = read = free for the next lap's producer.  Every wait is bounded (kQSpinLimit / the wall-clock watchdog): a logic error
 // ends the launch with an error flag (PT_ERR_DEVICE on the host) instead of hanging the GPU.
 // Bounds that keep the rings from deadlocking: paths in flight per workgroup <= q.target <= T-lanes + 2 x ring - 64 (host checks).
 #pragma once
@@ -35,10 +36,19 @@ namespace ptk {
 #define PT_Q_NS 3
 #endif
 #ifndef PT_Q_RING
-#define PT_Q_RING 128
+#define PT_Q_RING 256
 #endif
 #ifndef PT_Q_MINW
 #define PT_Q_MINW 6
+#endif
+#ifndef PT_Q_SPRIO
+#define PT_Q_SPRIO 2
+#endif
+#ifndef PT_Q_BURST_IN
+#define PT_Q_BURST_IN 6         // inner steps and
+#endif
+#ifndef PT_Q_BURST_LF
+#define PT_Q_BURST_LF 2         // leaf steps of a T-wave between two looks at the rings
 #endif
 constexpr int kQT = PT_Q_NT;                        // traversal waves per workgroup
 constexpr int kQS = PT_Q_NS;                        // shading waves per workgroup
@@ -121,16 +131,41 @@ struct QPath {
 constexpr uint32_t kQRedoBit = 0x80000000u;
 
 __device__ __forceinline__ unsigned char* q_entry(unsigned char* ring, uint32_t pos) {
-    return ring + (pos & (kQRing - 1)) * kQEntryBytes;
+    // An entry is kept as two halves of 48 B in two arrays (words 0..11 in the first, 12..23 — the sequence word among them —
+    // kQRing x 48 B further on): consecutive lanes move consecutive entries, and 128-bit LDS accesses 48 B apart touch every
+    // bank once, where a 96-B pitch put two lanes of each group on the same banks (40 % of the LDS cycles were conflicts).
+    return ring + (pos & (kQRing - 1)) * (kQEntryBytes / 2);
+}
+constexpr uint32_t kQHalf = kQRing * (kQEntryBytes / 2);      // byte distance between the two halves of an entry
+// Sequence word of position `pos` when it is free for its producer (see the header of this file).
+__device__ __forceinline__ uint32_t q_seq(uint32_t pos) { return (pos / kQRing) * 2u; }
+// ... and the sequence arithmetic wraps where the 32-bit positions do (after 2^32 / ring laps)
+constexpr uint32_t kQSeqMask = (uint32_t)((((1ull << 32) / kQRing) * 2ull) - 1ull);
+
+// error bits: 1 a bounded wait ran out, 2 an entry failed its check word, 4 a path carried an impossible primitive or sample index
+__device__ __forceinline__ void q_flag_error(lds_u32* ctl, uint32_t bits = 1u) { __hip_atomic_fetch_or(ctl + kQError, bits, __ATOMIC_RELAXED, PT_Q_WG); }
+#ifndef PT_Q_CHECK
+#define PT_Q_CHECK 0
+#endif
+__device__ __forceinline__ uint32_t q_check_word(const QPath& p) {
+    uint32_t h = 0x9e3779b9u;
+    auto mix = [&h](float f) { h = (h ^ __builtin_bit_cast(uint32_t, f)) * 0x01000193u; };
+    mix(p.org.x); mix(p.org.y); mix(p.org.z); mix(p.dir.x); mix(p.dir.y); mix(p.dir.z); mix(p.a0); mix(p.a1); mix(p.a2); mix(p.a3);
+    mix(p.L.x); mix(p.L.y); mix(p.L.z); mix(p.T.x); mix(p.T.y); mix(p.T.z);
+    h = (h ^ (uint32_t)p.rng.state) * 0x01000193u; h = (h ^ (uint32_t)(p.rng.state >> 32)) * 0x01000193u;
+    h = (h ^ (uint32_t)p.rng.inc) * 0x01000193u; h = (h ^ (uint32_t)(p.rng.inc >> 32)) * 0x01000193u;
+    h = (h ^ p.depth_flags) * 0x01000193u; h = (h ^ p.my_w) * 0x01000193u;
+    return h;
 }
 
-__device__ __forceinline__ void q_flag_error(lds_u32* ctl) { __hip_atomic_store(ctl + kQError, 1u, __ATOMIC_RELAXED, PT_Q_WG); }
-
 // Producer side of one entry (the position has been reserved): wait until its last reader is done, write, publish.
-__device__ __forceinline__ void q_write(unsigned char* e, const QPath& p, lds_u32* ctl) {
-    lds_u32* flag = (lds_u32*)(e + 88);
+__device__ __forceinline__ void q_write(unsigned char* ring, uint32_t pos, const QPath& p, lds_u32* ctl) {
+    unsigned char* e = q_entry(ring, pos);
+    unsigned char* e2 = e + kQHalf;
+    const uint32_t seq = q_seq(pos);
+    lds_u32* flag = (lds_u32*)(e2 + 40);
     uint32_t spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, PT_Q_WG) != 0u) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, PT_Q_WG) != seq) {
         if (++spins > kQSpinLimit) { q_flag_error(ctl); break; }
         __builtin_amdgcn_s_sleep(1);
     }
@@ -142,29 +177,39 @@ __device__ __forceinline__ void q_write(unsigned char* e, const QPath& p, lds_u3
     f4v v4 = {__builtin_bit_cast(float, (uint32_t)p.rng.state), __builtin_bit_cast(float, (uint32_t)(p.rng.state >> 32)),
               __builtin_bit_cast(float, (uint32_t)p.rng.inc), __builtin_bit_cast(float, (uint32_t)(p.rng.inc >> 32))};
     f2v v5 = {__builtin_bit_cast(float, p.depth_flags), __builtin_bit_cast(float, p.my_w)};
-    w[0] = v0; w[1] = v1; w[2] = v2; w[3] = v3; w[4] = v4;
-    *(lds_f2w*)(e + 80) = v5;
-    __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, PT_Q_WG);
+    lds_f4w* w2 = (lds_f4w*)e2;
+    w[0] = v0; w[1] = v1; w[2] = v2; w2[0] = v3; w2[1] = v4;
+    *(lds_f2w*)(e2 + 32) = v5;
+    if (PT_Q_CHECK) *(lds_u32*)(e2 + 44) = q_check_word(p);
+    __hip_atomic_store(flag, seq + 1u, __ATOMIC_RELEASE, PT_Q_WG);
 }
 
 // Consumer side (the position has been claimed): wait until the producer has published it, read, hand the entry back.
-__device__ __forceinline__ void q_read(unsigned char* e, QPath& p, lds_u32* ctl) {
-    lds_u32* flag = (lds_u32*)(e + 88);
+__device__ __forceinline__ void q_read(unsigned char* ring, uint32_t pos, QPath& p, lds_u32* ctl) {
+    unsigned char* e = q_entry(ring, pos);
+    unsigned char* e2 = e + kQHalf;
+    const uint32_t seq = q_seq(pos);
+    lds_u32* flag = (lds_u32*)(e2 + 40);
     uint32_t spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, PT_Q_WG) != 1u) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, PT_Q_WG) != seq + 1u) {
         if (++spins > kQSpinLimit) { q_flag_error(ctl); break; }
         __builtin_amdgcn_s_sleep(1);
     }
     const lds_f4w* w = (const lds_f4w*)e;
-    const f4v v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3], v4 = w[4];
-    const f2v v5 = *(const lds_f2w*)(e + 80);
+    const lds_f4w* w2 = (const lds_f4w*)e2;
+    const f4v v0 = w[0], v1 = w[1], v2 = w[2], v3 = w2[0], v4 = w2[1];
+    const f2v v5 = *(const lds_f2w*)(e2 + 32);
     p.org = ptm::mk(v0.x, v0.y, v0.z); p.dir = ptm::mk(v0.w, v1.x, v1.y);
     p.a0 = v1.z; p.a1 = v1.w; p.a2 = v2.x; p.a3 = v2.y;
     p.L = ptm::mk(v2.z, v2.w, v3.x); p.T = ptm::mk(v3.y, v3.z, v3.w);
-    p.rng.state = (uint64_t)__builtin_bit_cast(uint32_t, v4.x) | ((uint64_t)__builtin_bit_cast(uint32_t, v4.y) << 32);
-    p.rng.inc = (uint64_t)__builtin_bit_cast(uint32_t, v4.z) | ((uint64_t)__builtin_bit_cast(uint32_t, v4.w) << 32);
-    p.depth_flags = __builtin_bit_cast(uint32_t, v5.x); p.my_w = __builtin_bit_cast(uint32_t, v5.y);
-    __hip_atomic_store(flag, 0u, __ATOMIC_RELEASE, PT_Q_WG);
+    // (elements are copied into floats first: __builtin_bit_cast applied to an ext-vector element expression reads element 0)
+    const float s0 = v4.x, s1 = v4.y, s2 = v4.z, s3 = v4.w, d0 = v5.x, d1 = v5.y;
+    p.rng.state = (uint64_t)__builtin_bit_cast(uint32_t, s0) | ((uint64_t)__builtin_bit_cast(uint32_t, s1) << 32);
+    p.rng.inc = (uint64_t)__builtin_bit_cast(uint32_t, s2) | ((uint64_t)__builtin_bit_cast(uint32_t, s3) << 32);
+    p.depth_flags = __builtin_bit_cast(uint32_t, d0); p.my_w = __builtin_bit_cast(uint32_t, d1);
+    const uint32_t chk = PT_Q_CHECK ? *(lds_u32*)(e2 + 44) : 0u;
+    __hip_atomic_store(flag, (seq + 2u) & kQSeqMask, __ATOMIC_RELEASE, PT_Q_WG);
+    if (PT_Q_CHECK && chk != q_check_word(p)) q_flag_error(ctl, 2u);
 }
 
 // Counter slots of the regrouping kernel beyond [0..3] (paths, segments, node visits, leaf tests); STATS builds only:
@@ -219,7 +264,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
             if (STATS) dg[0]++;
             // ---- traversal burst: 6 inner steps, 2 leaf steps (the shape v2 uses for LDS-resident scenes)
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
+            for (int k = 0; k < PT_Q_BURST_IN; k++) {
                 if (STATS) {
                     const int n_in = __popcll(__ballot(tv.cur >= 0));
                     if (n_in) { dg[3]++; dg[4] += (unsigned)n_in; }
@@ -230,7 +275,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < PT_Q_BURST_LF; k++) {
                 if (STATS) {
                     const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != DONE));
                     if (n_lf) { dg[5]++; dg[6] += (unsigned)n_lf; }
@@ -245,9 +290,19 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
             const unsigned long long fin_m = __ballot(fin);
             const int n_fin = __popcll(fin_m);
             const int n_emp = __popcll(__ballot(!has));
-            if (n_fin + n_emp >= q.swap || n_fin + n_emp == 64) {
+            const int n_trav = 64 - n_fin - n_emp;
+            // Push when enough lanes have finished to be worth the ring's atomics (or nothing else is left to do); pull when
+            // there are rays to be had for enough empty lanes.  An exchange that could move nothing is not started: a wave
+            // whose lanes wait for rays only looks at the ring's cursors.
+            const bool do_push = n_fin > 0 && (n_fin >= q.swap || n_trav == 0);
+            uint32_t r_avail = 0;
+            if (n_emp > 0 || do_push) r_avail = q_load(ctl + kQrTail) - q_load(ctl + kQrHead);
+            const int holes = n_emp + (do_push ? n_fin : 0);
+            const int fill = (int)r_avail < holes ? (int)r_avail : holes;
+            const bool do_pull = fill > 0 && (do_push || fill >= q.swap || fill == holes || n_trav < 32);
+            if (do_push || do_pull || n_trav == 0) {
                 if (STATS) dg[1]++;
-                if (n_fin) {
+                if (do_push) {
                     uint32_t pos;
                     if (q_reserve(ctl + kQsHead, (uint32_t)n_fin, lane, pos)) {
                         if (fin) {
@@ -257,7 +312,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                             p.L = cL; p.T = cT; p.rng = crng;
                             p.depth_flags = cdepth | (tv.redo ? kQRedoBit : 0u);
                             p.my_w = cw;
-                            q_write(q_entry(shade_ring, pos + lane_rank(fin_m)), p, ctl);
+                            q_write(shade_ring, pos + lane_rank(fin_m), p, ctl);
                             has = false;
                         }
                         if (STATS) dg[2] += (unsigned)n_fin;
@@ -266,10 +321,10 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                 const unsigned long long emp_m = __ballot(!has);
                 const uint32_t want = (uint32_t)__popcll(emp_m);
                 uint32_t got = 0, pos = 0;
-                if (want) got = q_claim(ctl + kQrHead, want, 1u, lane, pos);
+                if (want && r_avail) got = q_claim(ctl + kQrHead, want, 1u, lane, pos);
                 if (!has && lane_rank(emp_m) < got) {
                     QPath p;
-                    q_read(q_entry(ready_ring, pos + lane_rank(emp_m)), p, ctl);
+                    q_read(ready_ring, pos + lane_rank(emp_m), p, ctl);
                     ray.org = p.org; ray.dir = p.dir;
                     cL = p.L; cT = p.T; crng = p.rng; cdepth = p.depth_flags & 0xffffu; cw = p.my_w;
                     const bool primary = cdepth == 0u;
@@ -305,6 +360,9 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
     } else {
         // ---------------------------------------------------------------------------------- shading role
         const int swave = wave - kQT;
+        // a finished path waits in the shade ring, and its T-lane successor waits for a ray, until an S-wave gets to it: the few
+        // S-waves go first when they have something to issue
+        __builtin_amdgcn_s_setprio(PT_Q_SPRIO);
         WorkFeed feed;
         feed_init(feed, rp);
         bool feed_open = true;
@@ -315,7 +373,8 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
         for (;;) {
             bool did = false;
             // ---- start paths (main.cu:32-44) while the workgroup is below its target
-            if (feed_open && (int32_t)q_load(ctl + kQLive) + 64 <= q.target) {
+            if (feed_open && (int32_t)q_load(ctl + kQLive) + 64 <= q.target &&
+                q_load(ctl + kQrTail) - q_load(ctl + kQrHead) + 64u <= kQRing) {
                 feed_reserve(feed, rp, work_counter, lane);
                 const uint32_t avail = feed.end - feed.cur;
                 if (avail == 0) {
@@ -332,27 +391,34 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                         if (!room) __hip_atomic_fetch_sub(ctl + kQLive, n, __ATOMIC_RELAXED, PT_Q_WG);
                     }
                     room = __builtin_amdgcn_readfirstlane(room);
-                    uint32_t pos = 0;
-                    const bool go = room && q_reserve(ctl + kQrHead, n, lane, pos);
-                    if (room && !go && lane == 0) __hip_atomic_fetch_sub(ctl + kQLive, n, __ATOMIC_RELAXED, PT_Q_WG);
-                    if (go) {
+                    if (room) {
+                        // the paths first, their places in the ring second: a T-wave may claim a place the moment it is
+                        // reserved and would then wait for all of this
+                        QPath p;
+                        p.org = ptm::mk(0, 0, 0); p.dir = ptm::mk(0, 0, 1); p.a0 = p.a1 = p.a2 = p.a3 = 0.0f;
+                        p.L = ptm::mk(0, 0, 0); p.T = ptm::mk(1, 1, 1); p.rng.state = 0; p.rng.inc = 1; p.depth_flags = 0; p.my_w = 0;
                         if ((uint32_t)lane < n) {
                             const PathStart ps = start_path(rp, feed.region, feed.cur + (uint32_t)lane);
-                            QPath p;
                             p.org = ps.ray.org; p.dir = ps.ray.dir;
                             const ptm::V3 inv = ptm::mk(1.0f / p.dir.x, 1.0f / p.dir.y, 1.0f / p.dir.z);     // trav_begin
                             p.a0 = inv.x; p.a1 = inv.y; p.a2 = inv.z; p.a3 = 0.0f;
-                            p.L = ptm::mk(0, 0, 0); p.T = ptm::mk(1, 1, 1);
                             p.rng = ps.rng;
                             const bool finite = __builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z);
                             p.depth_flags = (fbk && !finite) ? kQRedoBit : 0u;
                             p.my_w = ps.sample_index;
-                            q_write(q_entry(ready_ring, pos + (uint32_t)lane), p, ctl);
-                            n_paths++;
                         }
-                        feed.cur += n;
-                        did = true;
-                        if (STATS) dg[10]++;
+                        uint32_t pos = 0;
+                        if (q_reserve(ctl + kQrHead, n, lane, pos)) {
+                            if ((uint32_t)lane < n) {
+                                q_write(ready_ring, pos + (uint32_t)lane, p, ctl);
+                                n_paths++;
+                            }
+                            feed.cur += n;
+                            did = true;
+                            if (STATS) dg[10]++;
+                        } else if (lane == 0) {             // no room in the ring after all: these items are started later
+                            __hip_atomic_fetch_sub(ctl + kQLive, n, __ATOMIC_RELAXED, PT_Q_WG);
+                        }
                     }
                 }
             }
@@ -371,7 +437,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                     p.L = ptm::mk(0, 0, 0); p.T = ptm::mk(1, 1, 1); p.rng.state = 0; p.rng.inc = 1; p.depth_flags = 0; p.my_w = 0;
                     bool cont = false;
                     if (mine) {
-                        q_read(q_entry(shade_ring, pos + (uint32_t)lane), p, ctl);
+                        q_read(shade_ring, pos + (uint32_t)lane, p, ctl);
                         ptd::Ray ray;
                         ray.org = p.org; ray.dir = p.dir;
                         int depth = (int)(p.depth_flags & 0xffffu);
@@ -380,6 +446,12 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                         ray.tfar = primary ? __builtin_inff() : FLT_MAX;
                         ptd::Hit best;
                         best.t = p.a0; best.u = p.a1; best.v = p.a2; best.prim = __builtin_bit_cast(int32_t, p.a3);
+                        if (PT_Q_CHECK && (best.prim < -1 || best.prim >= scn.num_prims || p.my_w >= rp.total_work)) {
+                            // cannot happen; if it does, the frame is invalid (error flag) but no address is made from it
+                            q_flag_error(ctl, 4u);
+                            best.prim = -1;
+                            p.my_w = 0;
+                        }
                         if (fbk && (p.depth_flags & kQRedoBit)) {
                             // the closest hit of this ray depends on the visit order: traced the reference's way, to completion
                             ptd::TravStats st_redo;
@@ -417,7 +489,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                             if (++spins > kQSpinLimit || q_load(ctl + kQError) != 0u) { q_flag_error(ctl); break; }
                             __builtin_amdgcn_s_sleep(2);
                         }
-                        if (placed && mine && cont) q_write(q_entry(ready_ring, rpos + lane_rank(cont_m)), p, ctl);
+                        if (placed && mine && cont) q_write(ready_ring, rpos + lane_rank(cont_m), p, ctl);
                     }
                 }
             }
@@ -436,7 +508,8 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
     flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
     if (lane == 0) {
         unsigned long long* slot = counter_slot(counters);
-        if (q_load(ctl + kQError) != 0u) atomicAdd(&slot[15], 1ull);           // the host turns this into PT_ERR_DEVICE
+        const uint32_t err = q_load(ctl + kQError);
+        if (err != 0u) atomicOr(&slot[15], (unsigned long long)err);           // the host turns this into PT_ERR_DEVICE
         if (STATS) {
             atomicAdd(&slot[4], dg[0]); atomicAdd(&slot[5], dg[1]); atomicAdd(&slot[6], dg[2]); atomicAdd(&slot[7], dg[3]);
             atomicAdd(&slot[8], dg[4]); atomicAdd(&slot[9], dg[5]); atomicAdd(&slot[10], dg[6]); atomicAdd(&slot[11], dg[7]);

@@ -11,7 +11,8 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480, 16), "teapot": (640, 480, 16),
-           "buddha_standin": (1280, 960, 16), "dragon_standin": (960, 540, 16)}
+           "buddha_standin": (1280, 960, 16), "dragon_standin": (960, 540, 16), "scene4": (640, 480, 32),
+           "scene1_phong": (640, 480, 16)}
 
 
 def worker(scenes):

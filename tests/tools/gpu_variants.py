@@ -18,7 +18,7 @@ from pathtracer_cuda_interactive_amd import device as dev  # noqa: E402
 SC = os.path.join(REPO, "tests", "golden", "scenes")
 CONFIGS = {"cbox": (640, 480, 64), "bunny": (640, 480, 64), "scene1": (640, 480, 16), "teapot": (640, 480, 16), "scene4": (640, 480, 32),
            "scene1_phong": (640, 480, 16), "buddha_standin": (1280, 960, 256), "dragon_standin": (1920, 1080, 1024)}
-RESET = {"v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "blocks_per_cu": 0, "stats": 0, "lds_budget_kb": 0, "chunk": 0, "fast_tree": 1}
+RESET = {"kernel": 2, "q_target": 0, "q_swap": 0, "q_low": 0, "v2_thresh": 0, "v2_inner": 0, "v2_minw": 0, "blocks_per_cu": 0, "stats": 0, "lds_budget_kb": 0, "chunk": 0, "fast_tree": 1}
 
 
 def main():
