@@ -682,6 +682,7 @@ TraceFn pick_kernel_v2(int res, bool prune, bool stats, int spec, int thresh, in
 #define PT_V2(T, I, W) if (thresh == T && inner == I && minw == W) return pick_v2_ti<T, I, W>(res, prune, stats, spec);
     PT_V2(40, -6, 6) PT_V2(32, 4, 6) PT_V2(40, 4, 6) PT_V2(40, 3, 6) PT_V2(40, 162, 6)
     PT_V2(32, 1004, 6) PT_V2(32, 1231, 6)
+    PT_V2(32, 1231, 5) PT_V2(40, 162, 5)        // 96 VGPRs, 5 waves per SIMD: for the instantiations that spill under the 80-VGPR cap
 #undef PT_V2
     return nullptr;
 }
