@@ -223,8 +223,17 @@ int pt_bvh_build_device(const pt_scene_desc* desc, int method, pt_bvh_node* out_
 int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
                        double* out_build_ms);
 
+/* The same builder run on the GPU (csrc/pt_sweep_build.hip: level-synchronous segmented scans and reductions): the SAME tree,
+ * byte for byte — pt_scene_create uses it from 4,096 shapes up.  out_build_ms = device time (sorts to finished nodes, without the
+ * upload of the leaf boxes and the copy back).  PT_ERR_UNSUPPORTED for input that runs into the host builder's depth guard
+ * (2 log2 n + 16 levels): only the host builder holds the median-cut fallback for such branches. */
+int pt_bvh_build_sweep_device(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth,
+                              double* out_build_ms);
+
 /* Tuning knobs (all optional; none of them changes a bit of the rendered image):
- *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel
+ *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel, 3 paths regrouped
+ *                   across the waves of a workgroup through LDS rings (csrc/pt_kernel_q.h; LDS-resident scenes with exact traversal,
+ *                   anything else runs on 2; "q_target" / "q_swap" / "q_low" are its schedule knobs, 0 = automatic)
  *   "v2_thresh" / "v2_inner" / "v2_minw"   scheduler variant of kernel 2; 0 = automatic (by scene residency).
  *                   v2_inner: < 0 vote burst of -n steps; 1..9 n inner steps + 1 leaf step per burst; >= 100 encodes
  *                   rounds*100 + inner*10 + leaf steps (162 = 6 inner + 2 leaf steps); 1000 + burst = the same burst with
@@ -254,7 +263,10 @@ int pt_bvh_build_sweep(const pt_scene_desc* desc, pt_bvh_node* out_nodes, int32_
  * "fast_tree" (an internal tree exists), "fast_tree_on" (the next render uses it), "fast_tree_is_callers" (it is the caller's own
  * topology in internal form: the sweep tree did not win the probe), "fast_tree_depth",
  * "fast_tree_cost_permille" (probe-ray node visits, internal / caller's x 1000; 0 = none built), "stack_entries" (per lane),
- * "redo_segments" (with "stats": segments of the last frame traced on the caller's tree), "debug_reruns" (same for pt_debug_intersect). */
+ * "redo_segments" (with "stats": segments of the last frame traced on the caller's tree), "debug_reruns" (same for pt_debug_intersect),
+ * "kernel" / "block_threads" (what the last render ran on), "sweep_on_device" (the internal tree was built on the GPU),
+ * "create_us0".."create_us6" (wall microseconds of pt_scene_create: total, primitive records, caller's tree checked and re-laid,
+ * internal tree built, ... re-laid, uploads + probe, tie tables). */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
 int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
 

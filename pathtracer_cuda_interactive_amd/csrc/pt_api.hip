@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -18,6 +19,8 @@
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
 #include "pt_tree_sweep.h"
+#include "pt_sweep_build.h"
+#include "pt_scene_prep.h"
 #include "pt_kernels.h"
 #include "pt_kernel_q.h"
 
@@ -87,6 +90,7 @@ constexpr uint32_t kLdsSceneLimit = 36 * 1024;   // scenes up to this size (64-B
 constexpr uint32_t kOctNodeLimit = 24 * 1024;    // 8 octant copies of the node table must fit in this many bytes of LDS
 constexpr int kMaxStack = 64;                    // the reference's own cap (scene.h:251)
 constexpr int kMinInternalTree = 16;              // primitives below which no internal tree is built (a handful of nodes either way: scene1, 4 shapes, is 6 % slower with one)
+constexpr int kDeviceSweepMin = 4096;             // primitives from which the internal tree is built on the device (below: a few ms on the host either way)
 constexpr int kProbeRays = 32768;                // validate_and_build: rays that choose between the caller's tree and the internal one
 constexpr uint64_t kDefaultScratchBytes = 8ull << 30;   // per-sample scratch cap (3 % of the 288 GB of HBM): every sample pass
                                                         // pays the launch floor once (buddha stand-in 135.6 ms in 5 passes, 130.6 in 1)
@@ -104,6 +108,29 @@ constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band
 constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
 
 uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+// every float finite?  (leaf boxes that stayed on the device)
+__global__ void finite_kernel(const float* __restrict__ v, size_t n, unsigned int* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !__builtin_isfinite(v[i])) atomicAdd(bad, 1u);
+}
+bool boxes_finite_device(const float* v_dev, size_t n) {
+    unsigned int* bad = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&bad), sizeof(unsigned int)) != hipSuccess) return false;
+    unsigned int h = 1;
+    if (hipMemset(bad, 0, sizeof(unsigned int)) == hipSuccess) {
+        hipLaunchKernelGGL(finite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, v_dev, n, bad);
+        if (hipMemcpy(&h, bad, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) h = 1;
+    }
+    (void)hipFree(bad);
+    return h == 0;
+}
+
+// PT_SWEEP_BUILD=host in the environment keeps the internal tree's build on the host (A/B timing, debugging)
+bool host_sweep_forced() {
+    const char* v = std::getenv("PT_SWEEP_BUILD");
+    return v && std::string(v) == "host";
+}
 
 }  // namespace
 
@@ -166,6 +193,9 @@ struct pt_scene {
     int64_t opt_q_target = 0, opt_q_swap = 0, opt_q_low = 0;   // schedule knobs of kernel 3; 0 = automatic
     int64_t opt_v2_thresh = 0, opt_v2_inner = 0, opt_v2_minw = 0;   // 0 = auto (see pick_kernel)
     // info of last launch
+    // wall time of pt_scene_create's stages, microseconds: [0] total [1] primitive records [2] caller's tree checked and re-laid
+    // [3] internal tree built [4] ... re-laid [5] uploads + probe [6] tie tables; built_on_device: the sweep ran on the GPU
+    int64_t create_us[7] = {0, 0, 0, 0, 0, 0, 0}, sweep_on_device = 0;
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0, info_debug_reruns = 0, fast_cost_permille = 0, info_kernel = 0;
     struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
     // HIP events of the last `opt_timing_frames` render calls (a ring; default 1): a caller that enqueues frame after frame
@@ -381,9 +411,21 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     }
 
     // ---- primitives
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t0) { return (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count(); };
+    const clk::time_point t_all = clk::now();
+    clk::time_point t_stage = t_all;
     const int N = d->num_shapes;
-    std::vector<DPrim> prims(N);
-    std::vector<DNormals> normals(N);
+    const bool on_device = N >= kDeviceSweepMin && !host_sweep_forced();     // big scenes are prepared on the device (see below)
+    std::vector<DPrim> prims(on_device ? 0 : N);
+    std::vector<DNormals> normals(on_device ? 0 : N);
+    S->tri_only = true;
+    if (on_device) {
+        int prc, has_sphere = 0;
+        if ((prc = S->prims.ensure((size_t)N)) || (prc = S->normals.ensure((size_t)N))) return prc;
+        if ((prc = ptp::prims_device(d, S->prims.p, S->normals.p, &has_sphere))) return prc;
+        S->tri_only = !has_sphere;
+    } else {
     std::memset(prims.data(), 0, sizeof(DPrim) * N);
     std::memset(normals.data(), 0, sizeof(DNormals) * N);
     for (int i = 0; i < N; i++) {
@@ -394,6 +436,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             p.v[0] = s.center[0]; p.v[1] = s.center[1]; p.v[2] = s.center[2]; p.v[3] = s.radius;
             p.info = (int32_t)(0x80000000u | (uint32_t)s.material_id);
             p.light = s.area_light_id;
+            S->tri_only = false;
         } else if (s.type == PT_SHAPE_TRIANGLE) {
             if (s.mesh_index < 0 || s.mesh_index >= d->num_meshes) return fail(PT_ERR_BAD_SCENE, "triangle mesh index out of range");
             const pt_mesh& me = d->meshes[s.mesh_index];
@@ -412,45 +455,120 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             return fail(PT_ERR_BAD_SCENE, "unknown shape type");
         }
     }
+    }
 
     S->diffuse_only = true;
     for (int m = 0; m < d->num_materials; m++)
         if (d->materials[m].type != PT_MAT_DIFFUSE) { S->diffuse_only = false; break; }
-    S->tri_only = true;
-    for (int i = 0; i < N; i++)
-        if (d->shapes[i].type == PT_SHAPE_SPHERE) { S->tri_only = false; break; }
 
+    S->create_us[1] = us_since(t_stage); t_stage = clk::now();
     // ---- BVH: the caller's tree (validated), and the internal tree over the same leaf boxes
+    // From kDeviceSweepMin primitives up all of it happens on the device (pt_scene_prep.hip, pt_sweep_build.hip): the caller's
+    // pool goes up once, is checked and re-laid there, its leaf boxes feed the sweep builder, the builder's pool is re-laid in
+    // turn — nothing of either tree comes back to the host.  The host code below serves small scenes, PT_SWEEP_BUILD=host, and
+    // whatever the device path hands back (input that runs into the sweep builder's depth guard).
     TreeHost ref;
-    std::vector<float> leaf_boxes((size_t)N * 6);
-    bool nested = true;
-    int trc = convert_tree(d->nodes, d->num_nodes, d->root, N, ref, leaf_boxes.data(), &nested);
-    if (trc) return trc;
     TreeHost fast;
     bool have_fast = false;
-    if (N >= kMinInternalTree && nested) {
-        // A leaf is tested by the reference iff the ray hits every box on its way down (scene.h:278-297, no pruning).  The slab
-        // test is monotone in the box (rounding is), so where every box contains its children's that is: iff it hits the LEAF's
-        // own box — whatever the tree above it.  `nested` says the caller's tree is of that kind; then any tree over the same
-        // leaf boxes tests the same leaves, and only the ORDER of the tests (ties on t, scene.h:270) still depends on the tree.
-        // The tree: all cuts along x, y and z at every node (pt_tree_sweep.h), as deep as it likes — traversed left child
-        // first, its stack need is its Strahler number, not its depth (convert_tree).
-        bool finite = true;
-        for (size_t k = 0; k < leaf_boxes.size() && finite; k++) finite = std::isfinite(leaf_boxes[k]);
-        if (finite) {
-            std::vector<pt_bvh_node> fnodes;
-            int32_t froot = 0, fdepth = 0;
-            bool built = true;
-            try {
-                pts::build_sweep_tree(leaf_boxes.data(), N, fnodes, &froot, &fdepth);
-            } catch (const std::exception&) {        // out of host memory: the caller's tree serves alone
-                built = false;
+    bool trees_on_device = false;              // tree[0] (and tree[1] when have_fast) already sit in S->tree[]
+    int ref_depth = 0;
+    size_t ref_inner = 0;
+    DevBuf<pt_bvh_node> pool_dev;              // the caller's pool and the map pool index -> DNode index (tie tables)
+    DevBuf<int32_t> iop_dev;
+    S->sweep_on_device = 0;
+    if (on_device) {
+        DevBuf<float> boxes_dev;
+        ptp::RelayResult r0;
+        int prc;
+        if ((prc = pool_dev.ensure((size_t)d->num_nodes)) || (prc = iop_dev.ensure((size_t)d->num_nodes)) || (prc = boxes_dev.ensure((size_t)N * 6)) ||
+            (prc = S->tree[0].nodes.ensure((size_t)N - 1)))
+            return prc;
+        HIP_TRY(hipMemcpy(pool_dev.p, d->nodes, (size_t)d->num_nodes * sizeof(pt_bvh_node), hipMemcpyHostToDevice));
+        prc = ptp::relay_tree_device(pool_dev.p, d->num_nodes, d->root, N, false, S->tree[0].nodes.p, iop_dev.p, boxes_dev.p, kBlock, kTopNodes,
+                                     kMaxLdsBudget, &r0);
+        if (prc) return prc;                   // PT_ERR_BAD_SCENE with the host path's messages
+        {
+            pt_scene::Tree& T0 = S->tree[0];
+            T0.have_oct = false; T0.num_nodes = N - 1; T0.root_ref = 0; T0.stack_cap = r0.stack_need + 1; T0.top_avail = r0.top_avail; T0.depth = r0.depth;
+        }
+        ref_depth = r0.depth;
+        ref_inner = (size_t)N - 1;
+        trees_on_device = true;
+        S->create_us[2] = us_since(t_stage); t_stage = clk::now();
+        if (r0.nested) {
+            // (why a tree of the library's own may stand in for a nested caller's tree: see the host path below)
+            DevBuf<pt_bvh_node> fpool_dev;
+            DevBuf<int32_t> fiop_dev;
+            int32_t fdepth = 0;
+            double dev_ms = 0;
+            bool ok = !fpool_dev.ensure((size_t)d->num_nodes) && !fiop_dev.ensure((size_t)d->num_nodes) && !S->tree[1].nodes.ensure((size_t)N - 1) &&
+                      boxes_finite_device(boxes_dev.p, (size_t)N * 6) &&
+                      pts::sweep_build_on_device(boxes_dev.p, N, fpool_dev.p, &fdepth, &dev_ms) == PT_OK;
+            S->create_us[3] = us_since(t_stage); t_stage = clk::now();
+            ptp::RelayResult r1;
+            if (ok && ptp::relay_tree_device(fpool_dev.p, d->num_nodes, 0, N, true, S->tree[1].nodes.p, fiop_dev.p, nullptr, kBlock, kTopNodes,
+                                             kMaxLdsBudget, &r1) == PT_OK && r1.nested) {
+                pt_scene::Tree& T1 = S->tree[1];
+                T1.have_oct = false; T1.num_nodes = N - 1; T1.root_ref = 0; T1.stack_cap = r1.stack_need + 1; T1.top_avail = r1.top_avail; T1.depth = r1.depth;
+                have_fast = true;
+                S->sweep_on_device = 1;
+            } else {
+                (void)hipGetLastError();
+                S->tree[1].nodes.release();
+                {
+                    // the device builder handed the input back (depth guard) or failed: the host builder, from the leaf boxes
+                    std::vector<float> leaf_boxes((size_t)N * 6);
+                    std::vector<pt_bvh_node> fnodes;
+                    int32_t froot = 0, hdepth = 0;
+                    bool built = hipMemcpy(leaf_boxes.data(), boxes_dev.p, leaf_boxes.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+                    for (size_t k = 0; k < leaf_boxes.size() && built; k++) built = std::isfinite(leaf_boxes[k]);
+                    if (built) {
+                        try {
+                            pts::build_sweep_tree(leaf_boxes.data(), N, fnodes, &froot, &hdepth);
+                        } catch (const std::exception&) {
+                            built = false;
+                        }
+                    }
+                    bool fnested = true;
+                    have_fast = built && convert_tree(fnodes.data(), (int)fnodes.size(), froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
+                }
             }
-            bool fnested = true;
-            have_fast = built && convert_tree(fnodes.data(), (int)fnodes.size(), froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
+        }
+    } else {
+        std::vector<float> leaf_boxes((size_t)N * 6);
+        bool nested = true;
+        int trc = convert_tree(d->nodes, d->num_nodes, d->root, N, ref, leaf_boxes.data(), &nested);
+        if (trc) return trc;
+        ref_depth = ref.depth;
+        ref_inner = ref.nodes.size();
+        S->create_us[2] = us_since(t_stage); t_stage = clk::now();
+        if (N >= kMinInternalTree && nested) {
+            // A leaf is tested by the reference iff the ray hits every box on its way down (scene.h:278-297, no pruning).  The slab
+            // test is monotone in the box (rounding is), so where every box contains its children's that is: iff it hits the LEAF's
+            // own box — whatever the tree above it.  `nested` says the caller's tree is of that kind; then any tree over the same
+            // leaf boxes tests the same leaves, and only the ORDER of the tests (ties on t, scene.h:270) still depends on the tree.
+            // The tree: all cuts along x, y and z at every node (pt_tree_sweep.h), as deep as it likes — traversed left child
+            // first, its stack need is its Strahler number, not its depth (convert_tree).
+            bool finite = true;
+            for (size_t k = 0; k < leaf_boxes.size() && finite; k++) finite = std::isfinite(leaf_boxes[k]);
+            if (finite) {
+                std::vector<pt_bvh_node> fnodes;
+                int32_t froot = 0, fdepth = 0;
+                bool built = true;
+                try {
+                    pts::build_sweep_tree(leaf_boxes.data(), N, fnodes, &froot, &fdepth);
+                } catch (const std::exception&) {        // out of host memory: the caller's tree serves alone
+                    built = false;
+                }
+                S->create_us[3] = us_since(t_stage); t_stage = clk::now();
+                bool fnested = true;
+                have_fast = built && convert_tree(fnodes.data(), (int)fnodes.size(), froot, N, fast, nullptr, &fnested, true) == PT_OK && fnested;
+            }
         }
     }
-    const TreeHost* hosts[2] = {&ref, have_fast ? &fast : nullptr};
+    S->create_us[4] = us_since(t_stage); t_stage = clk::now();
+    // trees the device path made are in S->tree[] already; what the host made is uploaded below
+    const TreeHost* hosts[2] = {trees_on_device ? nullptr : &ref, (have_fast && !S->sweep_on_device) ? &fast : nullptr};
     std::vector<DMaterial> mats(d->num_materials);
     for (int m = 0; m < d->num_materials; m++) {
         const pt_material& src = d->materials[m];
@@ -505,14 +623,15 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
     for (int t = 0; t < 2; t++)
         if (hosts[t] && (rc = upload_tree(t, *hosts[t]))) return rc;
     S->have_fast = have_fast;
-    if ((rc = S->prims.ensure(prims.size()))) return rc;
-    if ((rc = S->normals.ensure(normals.size()))) return rc;
+    if (!on_device && ((rc = S->prims.ensure(prims.size())) || (rc = S->normals.ensure(normals.size())))) return rc;
     if ((rc = S->materials.ensure(mats.size()))) return rc;
     if ((rc = S->emission.ensure(emis.size()))) return rc;
     if ((rc = S->lights.ensure(dlights.size()))) return rc;
     HIP_TRY(hipMemcpy(S->lights.p, dlights.data(), dlights.size() * sizeof(DLight), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S->prims.p, prims.data(), prims.size() * sizeof(DPrim), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S->normals.p, normals.data(), normals.size() * sizeof(DNormals), hipMemcpyHostToDevice));
+    if (!on_device) {
+        HIP_TRY(hipMemcpy(S->prims.p, prims.data(), prims.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S->normals.p, normals.data(), normals.size() * sizeof(DNormals), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(S->materials.p, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(S->emission.p, emis.data(), emis.size() * sizeof(DEmission), hipMemcpyHostToDevice));
 
@@ -551,7 +670,7 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             // children ordered for a short stack, leaves set aside, ties settled in place.  So the caller's own topology becomes the
             // internal tree (a caller who hands in a tree as good as the sweep tree: 5.43 -> 4.9 ms on bunny,
             // profiles/r02_device_bvh_build.log).
-            const bool global_scene = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref.nodes.size() * sizeof(DNode) > kLdsSceneLimit;
+            const bool global_scene = (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + ref_inner * sizeof(DNode) > kLdsSceneLimit;
             if (global_scene) {
                 TreeHost own;
                 bool own_nested = true;
@@ -563,31 +682,13 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             }
         }
     }
+    S->create_us[5] = us_since(t_stage); t_stage = clk::now();
     if (S->have_fast) {
         // what settles ties on t in the caller's visit order: every primitive's path from the caller's root (turn bits) and
         // the inner nodes along it.  (Depth <= 64 levels of leaves and inner nodes: at most 63 turns.)
-        const int levels = std::max(ref.depth - 1, 1);
-        std::vector<unsigned long long> path(N, 0ull);
-        std::vector<int32_t> anc((size_t)N * levels, 0);
-        struct Walk { int32_t node; int32_t level; unsigned long long turns; };
-        std::vector<Walk> todo;
-        std::vector<int32_t> trail(levels, 0);
-        todo.push_back({d->root, 0, 0ull});
-        while (!todo.empty()) {
-            const Walk w = todo.back();
-            todo.pop_back();
-            const pt_bvh_node& nd = d->nodes[w.node];
-            if (nd.prim != -1) {
-                path[nd.prim] = w.turns;
-                std::memcpy(&anc[(size_t)nd.prim * levels], trail.data(), (size_t)w.level * sizeof(int32_t));
-                continue;
-            }
-            trail[w.level] = ref.inner_of_pool[w.node];
-            // depth-first, left subtree first: `trail` below w.level is still this node's path when its right child is taken up
-            todo.push_back({nd.right, w.level + 1, w.turns | (1ull << w.level)});
-            todo.push_back({nd.left, w.level + 1, w.turns});
-        }
-        if (S->ref_path.ensure(path.size()) || S->ref_anc.ensure(anc.size())) {
+        const int levels = std::max(ref_depth - 1, 1);
+        const size_t anc_words = (size_t)N * (size_t)levels;
+        if (S->ref_path.ensure((size_t)N) || S->ref_anc.ensure(anc_words)) {
             // no room for the tables (num_shapes x depth words): the scene simply keeps to the caller's tree
             (void)hipGetLastError();
             S->have_fast = false;
@@ -595,14 +696,48 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             S->ref_path.release(); S->ref_anc.release();
             S->tree[1].nodes.release(); S->tree[1].nodes_oct.release(); S->tree[1].have_oct = false;
         } else {
-            HIP_TRY(hipMemcpy(S->ref_path.p, path.data(), path.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(S->ref_anc.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            bool made = false;
+            if (trees_on_device) {
+                // on the device: every leaf of the caller's pool (uploaded above) walks to the root (pt_scene_prep.hip) — a
+                // depth-first walk over a million leaves writing a 100 MB table is 150 ms of host time, and the table would
+                // have to be uploaded
+                DevBuf<int32_t> parent_dev;
+                if (!parent_dev.ensure((size_t)d->num_nodes) && hipMemset(S->ref_anc.p, 0, anc_words * sizeof(int32_t)) == hipSuccess)
+                    made = ptp::tie_tables_device(pool_dev.p, d->num_nodes, d->root, iop_dev.p, N, levels, parent_dev.p, S->ref_path.p, S->ref_anc.p) == PT_OK;
+                if (!made) return fail(PT_ERR_DEVICE, "tie tables on the device failed");
+            }
+            if (!made) {
+                std::vector<unsigned long long> path(N, 0ull);
+                std::vector<int32_t> anc(anc_words, 0);
+                struct Walk { int32_t node; int32_t level; unsigned long long turns; };
+                std::vector<Walk> todo;
+                std::vector<int32_t> trail(levels, 0);
+                todo.push_back({d->root, 0, 0ull});
+                while (!todo.empty()) {
+                    const Walk w = todo.back();
+                    todo.pop_back();
+                    const pt_bvh_node& nd = d->nodes[w.node];
+                    if (nd.prim != -1) {
+                        path[nd.prim] = w.turns;
+                        std::memcpy(&anc[(size_t)nd.prim * levels], trail.data(), (size_t)w.level * sizeof(int32_t));
+                        continue;
+                    }
+                    trail[w.level] = ref.inner_of_pool[w.node];
+                    // depth-first, left subtree first: `trail` below w.level is still this node's path when its right child is taken up
+                    todo.push_back({nd.right, w.level + 1, w.turns | (1ull << w.level)});
+                    todo.push_back({nd.left, w.level + 1, w.turns});
+                }
+                HIP_TRY(hipMemcpy(S->ref_path.p, path.data(), path.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(S->ref_anc.p, anc.data(), anc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
             S->ref_levels = levels;
         }
     }
+    S->create_us[6] = us_since(t_stage);
+    S->create_us[0] = us_since(t_all);
     select_tree(S, 0);
     S->scene_bytes = (uint32_t)std::min<size_t>(
-        ref.nodes.size() * sizeof(DNode) + prims.size() * (sizeof(DPrim) + sizeof(DNormals)) + mats.size() * sizeof(DMaterial) +
+        ref_inner * sizeof(DNode) + (size_t)N * (sizeof(DPrim) + sizeof(DNormals)) + mats.size() * sizeof(DMaterial) +
             emis.size() * sizeof(DEmission) + 64, 0xffffffffu);
     return PT_OK;
 }
@@ -1212,6 +1347,8 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k == "num_inner_nodes") *value = S->tree[0].num_nodes;
     else if (k == "top_nodes") { const int w = which_tree(S); *value = make_plan(S, scene_residency(S, w), false, w).top_count; }
     else if (k == "device") *value = S->device;
+    else if (k == "sweep_on_device") *value = S->sweep_on_device;         // the internal tree was built on the GPU (pt_sweep_build.hip)
+    else if (k.rfind("create_us", 0) == 0 && k.size() == 10 && k[9] >= '0' && k[9] <= '6') *value = S->create_us[k[9] - '0'];
     else if (k == "kernel") *value = S->info_kernel;                      // the kernel the last render ran on (1, 2 or 3)
     else if (k == "block_threads") *value = S->info_kernel == 3 ? kQBlock : kBlock;
     else if (k.rfind("qdiag", 0) == 0 && k.size() >= 6 && k.size() <= 7 && k.find_first_not_of("0123456789", 5) == std::string::npos &&
@@ -1328,6 +1465,36 @@ int pt_bvh_build_sweep(const pt_scene_desc* d, pt_bvh_node* out_nodes, int32_t* 
     *out_root = root;
     if (out_depth) *out_depth = depth;
     if (out_build_ms) *out_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+int pt_bvh_build_sweep_device(const pt_scene_desc* d, pt_bvh_node* out_nodes, int32_t* out_root, int32_t* out_depth, double* out_build_ms) {
+    if (!d || !out_nodes || !out_root) return fail(PT_ERR_INVALID_ARG, "bad argument");
+    const int N = d->num_shapes;
+    if (N <= 0 || !d->nodes || d->num_nodes != 2 * N - 1) return fail(PT_ERR_BAD_SCENE, "needs the leaf boxes of a 2*num_shapes-1 node pool");
+    std::vector<float> boxes((size_t)N * 6);
+    std::vector<char> seen(N, 0);
+    for (int k = 0; k < d->num_nodes; k++) {
+        const pt_bvh_node& nd = d->nodes[k];
+        if (nd.prim == -1) continue;
+        if (nd.prim < 0 || nd.prim >= N || seen[nd.prim]) return fail(PT_ERR_BAD_SCENE, "leaves must cover every shape exactly once");
+        seen[nd.prim] = 1;
+        std::memcpy(&boxes[(size_t)nd.prim * 6], nd.bmin, 12);
+        std::memcpy(&boxes[(size_t)nd.prim * 6 + 3], nd.bmax, 12);
+    }
+    for (int i = 0; i < N; i++)
+        if (!seen[i]) return fail(PT_ERR_BAD_SCENE, "leaves must cover every shape exactly once");
+    for (float v : boxes)
+        if (!std::isfinite(v)) return fail(PT_ERR_BAD_SCENE, "leaf box is not finite");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    std::vector<pt_bvh_node> nodes;
+    int32_t root = 0, depth = 0;
+    int rc = pts::sweep_build_device(boxes.data(), N, nodes, &root, &depth, out_build_ms);
+    if (rc) return rc;
+    std::memcpy(out_nodes, nodes.data(), nodes.size() * sizeof(pt_bvh_node));
+    *out_root = root;
+    if (out_depth) *out_depth = depth;
     return PT_OK;
 }
 

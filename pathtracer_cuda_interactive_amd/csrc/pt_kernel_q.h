@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
     constexpr int32_t DONE = ptd::done_value<STK>();
     const bool fbk = scn.fallback != 0;
     unsigned long long idle_since = 0;       // wall clock (100 MHz) when this wave last ran out of things to do; 0 = it is busy
-    uint32_t n_paths = 0, n_segs = 0;
+    uint32_t n_paths = 0, n_segs = 0, n_redo = 0;
     ptd::TravStats st;
     st.nodes = 0; st.leaves = 0;
     unsigned long long dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                             ptd::TravStats st_redo;
                             st_redo.nodes = 0; st_redo.leaves = 0;
                             best = ptd::intersect<false, false>(sv_ref, ray, redo_stk, st_redo);
-                            if (STATS) dg[8]++;
+                            if (STATS) n_redo++;
                         }
                         if (best.prim < 0) {
                             p.L = p.L + p.T * sv.bg;
@@ -506,6 +506,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
         }
     }
     flush_counters<STATS>(counters, lane, n_paths, n_segs, st);
+    dg[8] = STATS ? wave_sum(n_redo) : 0ull;                 // segments traced on the caller's tree (as v2's slot 12)
     if (lane == 0) {
         unsigned long long* slot = counter_slot(counters);
         const uint32_t err = q_load(ctl + kQError);

@@ -1,0 +1,384 @@
+// pt_sweep_build.hip — the library's internal tree (pt_tree_sweep.h: pts::build_sweep_tree) built ON THE DEVICE, byte for byte
+// the tree the host builder makes.
+//
+// The host builder (the CPU-side checker of this file; 76 ms for bunny's 288 k primitives and 306 ms for the 1.15 M of the buddha
+// stand-in on 8 host threads) is a top-down full-sweep surface-area build: at every node the primitives are swept along x, y
+// and z in centroid order and the cut with the smallest  SA(left) n_left + SA(right) n_right  wins, ties by distance from the
+// middle, then axis, then position.  The reference's own construct_bvh (bvh.cu:16-54) is host code too (README.md:123,132:
+// 10-57 s of start-up); nothing here follows it — this is the producer of the tree the hot path (scene.h:246-301 as restated
+// in pt_trace.h) traverses by default.
+//
+// Level-synchronous formulation, every node of a level at once, everything a streaming pass over n elements:
+//   * three orders of the primitives by (centroid, id) — 64-bit radix sorts (rocPRIM), the boxes travel with their order;
+//   * every node of the tree is the same range [b, e) of all three orders; a position knows its node by b (its scan key);
+//   * per axis: the boxes of all prefixes and of all suffixes of every range = two segmented scans (min / max do not round, the
+//     scan's operator keeps the EARLIER operand on ties exactly as the host's sequential merge does, so the very bits — the
+//     sign of a zero included — are the host's); cost of the cut after position i in fp64 with the host's operand order;
+//   * best cut of every node = a reduction by key over (cost, |2k - m|, axis, k), a total order: any reduction tree gives the
+//     host's choice;
+//   * the two other orders follow by a stable partition per node = an exclusive segmented scan of the "goes left" flags;
+//   * a node's slot in the pre-order output follows from its parent's: left = slot + 1, right = slot + 2 k.
+// One level costs ~35 small launches whatever n is; the levels of a million-primitive tree take a few milliseconds together.
+// Adversarial input (a branch deeper than 2 log2 n + 16, where the host builder switches to median cuts) is handed back to
+// the host builder: PT_ERR_UNSUPPORTED from sweep_build_device, never a different tree.
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+#include <rocprim/device/device_scan_by_key.hpp>
+#include <rocprim/iterator/reverse_iterator.hpp>
+
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "pt_internal.h"
+#include "pt_sweep_build.h"
+
+namespace {
+
+#define HIPS(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return pt_fail(e_ == hipErrorNoDevice ? PT_ERR_NO_DEVICE : PT_ERR_DEVICE,                \
+                           std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+struct SB {                     // pts::SBox
+    float lo[3], hi[3];
+};
+
+// pts::sbox_merge(a, b) with a = the operand that came EARLIER in the sequential sweep: b replaces a only when strictly
+// smaller (larger), so equal values — +0 and -0 — keep the earlier one's bits
+struct MergeKeepFirst {
+    __host__ __device__ SB operator()(const SB& a, const SB& b) const {
+        SB r;
+        for (int k = 0; k < 3; k++) {
+            r.lo[k] = b.lo[k] < a.lo[k] ? b.lo[k] : a.lo[k];
+            r.hi[k] = b.hi[k] > a.hi[k] ? b.hi[k] : a.hi[k];
+        }
+        return r;
+    }
+};
+
+// the host's sweeps start from sbox_empty() = (+3e38, -3e38): what a sweep holds is min(3e38, ...) / max(-3e38, ...)
+__device__ __forceinline__ SB clamp_like_host(const SB& b) {
+    SB r;
+    for (int k = 0; k < 3; k++) {
+        r.lo[k] = b.lo[k] < 3.0e38f ? b.lo[k] : 3.0e38f;
+        r.hi[k] = b.hi[k] > -3.0e38f ? b.hi[k] : -3.0e38f;
+    }
+    return r;
+}
+__device__ __forceinline__ double area_like_host(const SB& b) {       // pts::sbox_area
+    const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+    return 2.0 * (x * y + y * z + z * x);
+}
+
+struct Cand {                   // a cut of a node: total order (cost, off, axis, k)
+    double cost;
+    int32_t off;
+    int32_t ak;                 // axis << 28 | k
+};
+struct CandMin {
+    __host__ __device__ Cand operator()(const Cand& a, const Cand& b) const {
+        if (b.cost < a.cost) return b;
+        if (a.cost < b.cost) return a;
+        if (b.off != a.off) return b.off < a.off ? b : a;
+        return b.ak < a.ak ? b : a;
+    }
+};
+__device__ __forceinline__ Cand cand_none() { return Cand{__builtin_huge_val(), 0x7fffffff, 0x7fffffff}; }
+
+// ---- the three orders ------------------------------------------------------------------------------------------------------
+__global__ void sort_keys_kernel(const SB* __restrict__ boxes, int n, int axis, unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c = (boxes[i].lo[axis] + boxes[i].hi[axis]) * 0.5f;            // pt_tree_sweep.h: cen
+    if (c == 0.0f) c = 0.0f;                                             // -0 and +0 compare equal on the host: one key
+    uint32_t u = __builtin_bit_cast(uint32_t, c);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                      // unsigned order = float order
+    keys[i] = ((unsigned long long)u << 32) | (unsigned long long)(uint32_t)i;      // (centroid, id): a total order
+}
+__global__ void gather_order_kernel(const unsigned long long* __restrict__ keys, const SB* __restrict__ boxes, int n,
+                                    int32_t* __restrict__ idx, SB* __restrict__ bx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = (int32_t)(uint32_t)keys[i];
+    idx[i] = p;
+    bx[i] = boxes[p];
+}
+
+// ---- one level ---------------------------------------------------------------------------------------------------------------
+struct Level {                  // per position (same for all three orders)
+    uint32_t* seg_b;            // start of the node's range = the scan key
+    uint32_t* seg_e;            // its end
+};
+
+// Cuts along `axis`: the candidate of position i = the cut after i (k = i - b + 1 primitives go left), folded into best[i].
+// axis 0 also records the box of the whole node at its first position.
+__global__ void cand_kernel(const SB* __restrict__ pre, const SB* __restrict__ suf, const uint32_t* __restrict__ seg_b,
+                            const uint32_t* __restrict__ seg_e, int n, int axis, Cand* __restrict__ best, SB* __restrict__ whole) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = seg_b[i], e = seg_e[i];
+    if (axis == 0 && (uint32_t)i == b) whole[b] = clamp_like_host(suf[i]);
+    Cand c = cand_none();
+    if ((uint32_t)i + 1 < e) {
+        const int k = i - (int)b + 1, m = (int)(e - b);
+        c.cost = area_like_host(clamp_like_host(pre[i])) * k + area_like_host(clamp_like_host(suf[i + 1])) * (m - k);
+        c.off = 2 * k > m ? 2 * k - m : m - 2 * k;
+        c.ak = (axis << 28) | k;
+    }
+    best[i] = axis == 0 ? c : CandMin()(best[i], c);
+}
+
+struct BuildCtl {
+    unsigned int active;        // nodes of the next level with more than one primitive
+    unsigned int too_deep;      // a node beyond the host builder's depth guard: hand the build back
+    int max_depth;
+    unsigned int pad;
+};
+
+// One thread per node of the level (the reduction's output j): emit it, split it.
+__global__ void apply_kernel(const uint32_t* __restrict__ uniq_b, const Cand* __restrict__ best, const unsigned int* __restrict__ n_seg,
+                             const uint32_t* __restrict__ seg_e, const SB* __restrict__ whole, const int32_t* __restrict__ idx0,
+                             const SB* __restrict__ bx0, int32_t* __restrict__ slot, int32_t* __restrict__ split,
+                             pt_bvh_node* __restrict__ out, int depth, int guard_depth, BuildCtl* __restrict__ ctl) {
+    const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *n_seg) return;
+    const uint32_t b = uniq_b[j], e = seg_e[b];
+    const int m = (int)(e - b);
+    const int32_t s = slot[b];
+    if (m == 1) {
+        split[b] = 0;                                   // axis 0, k = 0: the partition below leaves the position where it is
+        if (s >= 0) {                                   // a leaf not written yet
+            pt_bvh_node nd;
+            for (int k = 0; k < 3; k++) { nd.bmin[k] = bx0[b].lo[k]; nd.bmax[k] = bx0[b].hi[k]; }
+            nd.left = -1; nd.right = -1; nd.prim = idx0[b];
+            out[s] = nd;
+            slot[b] = -1;
+            atomicMax(&ctl->max_depth, depth);
+        }
+        return;
+    }
+    if (depth > guard_depth) { atomicAdd(&ctl->too_deep, 1u); split[b] = 0; return; }
+    const Cand c = best[j];
+    const int axis = c.ak >> 28, k = c.ak & 0x0fffffff;
+    pt_bvh_node nd;
+    for (int q = 0; q < 3; q++) { nd.bmin[q] = whole[b].lo[q]; nd.bmax[q] = whole[b].hi[q]; }
+    nd.prim = -1;
+    nd.left = s + 1;
+    nd.right = s + 2 * k;                               // the left subtree holds 2 k - 1 nodes
+    out[s] = nd;
+    atomicMax(&ctl->max_depth, depth);
+    split[b] = (axis << 28) | k;
+    slot[b] = s + 1;                                    // the children's slots, by their first positions
+    slot[b + (uint32_t)k] = s + 2 * k;
+    unsigned int more = (k > 1 ? 1u : 0u) + (m - k > 1 ? 1u : 0u);
+    if (k == 1 || m - k == 1) more += 1u;               // a fresh leaf still has to be written: one more level
+    if (more) atomicAdd(&ctl->active, more);
+}
+
+// the first k positions of the chosen axis' order are the left set
+__global__ void mark_left_kernel(const uint32_t* __restrict__ seg_b, const int32_t* __restrict__ split, const int32_t* __restrict__ idx0,
+                                 const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2, int n, unsigned char* __restrict__ left) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = seg_b[i];
+    const int32_t sp = split[b];
+    const int axis = sp >> 28, k = sp & 0x0fffffff;
+    if (i - (int)b < k) {
+        const int32_t* ix = axis == 0 ? idx0 : axis == 1 ? idx1 : idx2;
+        left[ix[i]] = 1;
+    }
+}
+__global__ void flags_kernel(const int32_t* __restrict__ idx, const unsigned char* __restrict__ left, int n, uint32_t* __restrict__ f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = left[idx[i]];
+}
+// stable partition of every range by the flags (rank = exclusive segmented sum of the flags); order 0 also moves the ranges
+__global__ void scatter_kernel(const int32_t* __restrict__ idx, const SB* __restrict__ bx, const uint32_t* __restrict__ f,
+                               const uint32_t* __restrict__ rank, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
+                               const int32_t* __restrict__ split, int n, int32_t* __restrict__ idx_out, SB* __restrict__ bx_out,
+                               uint32_t* __restrict__ seg_b_out, uint32_t* __restrict__ seg_e_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = seg_b[i], e = seg_e[i];
+    const uint32_t k = (uint32_t)(split[b] & 0x0fffffff);
+    const uint32_t r = rank[i];
+    const uint32_t dest = f[i] ? b + r : b + k + ((uint32_t)i - b - r);
+    idx_out[dest] = idx[i];
+    bx_out[dest] = bx[i];
+    if (seg_b_out) {
+        seg_b_out[dest] = f[i] ? b : b + k;
+        seg_e_out[dest] = f[i] ? b + k : e;
+    }
+}
+__global__ void init_segments_kernel(int n, uint32_t* __restrict__ seg_b, uint32_t* __restrict__ seg_e, int32_t* __restrict__ slot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    seg_b[i] = 0u;
+    seg_e[i] = (uint32_t)n;
+    slot[i] = i == 0 ? 0 : -1;
+}
+
+template <class T>
+struct Buf {
+    T* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void**>(&p), (count ? count : 1) * sizeof(T)); }
+};
+
+}  // namespace
+
+int pts::sweep_build_device(const float* leaf_boxes, int n, std::vector<pt_bvh_node>& out, int32_t* out_root, int32_t* out_depth,
+                            double* out_device_ms) {
+    if (!leaf_boxes || n <= 0 || n >= (1 << 28)) return pt_fail(PT_ERR_INVALID_ARG, "sweep_build_device: bad argument");
+    Buf<SB> boxes;
+    Buf<pt_bvh_node> nodes;
+    HIPS(boxes.alloc(n));
+    HIPS(nodes.alloc((size_t)2 * n - 1));
+    HIPS(hipMemcpy(boxes.p, leaf_boxes, (size_t)n * sizeof(SB), hipMemcpyHostToDevice));
+    int rc = sweep_build_on_device(reinterpret_cast<const float*>(boxes.p), n, nodes.p, out_depth, out_device_ms);
+    if (rc) return rc;
+    out.assign((size_t)2 * n - 1, pt_bvh_node{});
+    HIPS(hipMemcpy(out.data(), nodes.p, out.size() * sizeof(pt_bvh_node), hipMemcpyDeviceToHost));
+    *out_root = 0;
+    return PT_OK;
+}
+
+int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* nodes_dev, int32_t* out_depth, double* out_device_ms) {
+    if (!leaf_boxes_dev || !nodes_dev || n <= 0 || n >= (1 << 28)) return pt_fail(PT_ERR_INVALID_ARG, "sweep_build_on_device: bad argument");
+    struct { const SB* p; } boxes{reinterpret_cast<const SB*>(leaf_boxes_dev)};
+    struct { pt_bvh_node* p; } nodes{nodes_dev};
+    const int T = 256, G = (n + T - 1) / T;
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    const int guard_depth = 2 * lg + 16;                     // pt_tree_sweep.h: beyond this the host builder cuts at the median
+
+    // One allocation for all working arrays (some thirty of them: a hipMalloc each would cost more than several levels of the build)
+    struct Arena {
+        unsigned char* base = nullptr;
+        size_t used = 0;
+        ~Arena() { if (base) (void)hipFree(base); }
+        size_t reserve(size_t bytes) { const size_t at = used; used += (bytes + 255) & ~(size_t)255; return at; }
+    } arena;
+    struct { SB* p; } bx[3], bx_alt[3], pre, suf, whole;
+    struct { int32_t* p; } idx[3], idx_alt[3], slot, split;
+    struct { unsigned long long* p; } keys, keys_alt;
+    struct { uint32_t* p; } seg_b, seg_e, seg_b_alt, seg_e_alt, flags, rank, uniq;
+    struct { Cand* p; } best, best_seg;
+    struct { unsigned char* p; } left, temp;
+    struct { BuildCtl* p; } ctl;
+    struct { unsigned int* p; } n_seg;
+    // temporary storage of the rocPRIM calls: the largest of the five kinds, sized once (size queries read no memory)
+    size_t t_sort = 0, t_scan_box = 0, t_scan_box_r = 0, t_scan_u = 0, t_reduce = 0;
+    {
+        unsigned long long* k64 = nullptr; uint32_t* k32 = nullptr; SB* sb = nullptr; Cand* cd = nullptr; unsigned int* cnt = nullptr;
+        HIPS(rocprim::radix_sort_keys(nullptr, t_sort, k64, k64, (size_t)n, 0, 64, nullptr));
+        HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box, k32, sb, sb, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
+        auto kr = rocprim::make_reverse_iterator(k32 + n);
+        auto vr = rocprim::make_reverse_iterator(sb + n);
+        HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box_r, kr, vr, vr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
+        HIPS(rocprim::exclusive_scan_by_key(nullptr, t_scan_u, k32, k32, k32, 0u, (size_t)n, rocprim::plus<uint32_t>(), rocprim::equal_to<uint32_t>(), nullptr));
+        HIPS(rocprim::reduce_by_key(nullptr, t_reduce, k32, cd, (size_t)n, k32, cd, cnt, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
+    }
+    const size_t t_bytes = std::max(std::max(std::max(t_sort, t_scan_box), std::max(t_scan_box_r, t_scan_u)), t_reduce);
+    const size_t nn = (size_t)n;
+    size_t o_bx[3], o_bxa[3], o_idx[3], o_idxa[3];
+    for (int a = 0; a < 3; a++) { o_bx[a] = arena.reserve(nn * sizeof(SB)); o_bxa[a] = arena.reserve(nn * sizeof(SB)); o_idx[a] = arena.reserve(nn * 4); o_idxa[a] = arena.reserve(nn * 4); }
+    const size_t o_pre = arena.reserve(nn * sizeof(SB)), o_suf = arena.reserve(nn * sizeof(SB)), o_whole = arena.reserve(nn * sizeof(SB));
+    const size_t o_slot = arena.reserve(nn * 4), o_split = arena.reserve(nn * 4), o_keys = arena.reserve(nn * 8), o_keysa = arena.reserve(nn * 8);
+    const size_t o_sb = arena.reserve(nn * 4), o_se = arena.reserve(nn * 4), o_sba = arena.reserve(nn * 4), o_sea = arena.reserve(nn * 4);
+    const size_t o_flags = arena.reserve(nn * 4), o_rank = arena.reserve(nn * 4), o_uniq = arena.reserve(nn * 4);
+    const size_t o_best = arena.reserve(nn * sizeof(Cand)), o_bests = arena.reserve(nn * sizeof(Cand)), o_left = arena.reserve(nn);
+    const size_t o_ctl = arena.reserve(sizeof(BuildCtl)), o_nseg = arena.reserve(sizeof(unsigned int)), o_temp = arena.reserve(t_bytes);
+    HIPS(hipMalloc(reinterpret_cast<void**>(&arena.base), arena.used));
+    for (int a = 0; a < 3; a++) {
+        bx[a].p = reinterpret_cast<SB*>(arena.base + o_bx[a]); bx_alt[a].p = reinterpret_cast<SB*>(arena.base + o_bxa[a]);
+        idx[a].p = reinterpret_cast<int32_t*>(arena.base + o_idx[a]); idx_alt[a].p = reinterpret_cast<int32_t*>(arena.base + o_idxa[a]);
+    }
+    pre.p = reinterpret_cast<SB*>(arena.base + o_pre); suf.p = reinterpret_cast<SB*>(arena.base + o_suf); whole.p = reinterpret_cast<SB*>(arena.base + o_whole);
+    slot.p = reinterpret_cast<int32_t*>(arena.base + o_slot); split.p = reinterpret_cast<int32_t*>(arena.base + o_split);
+    keys.p = reinterpret_cast<unsigned long long*>(arena.base + o_keys); keys_alt.p = reinterpret_cast<unsigned long long*>(arena.base + o_keysa);
+    seg_b.p = reinterpret_cast<uint32_t*>(arena.base + o_sb); seg_e.p = reinterpret_cast<uint32_t*>(arena.base + o_se);
+    seg_b_alt.p = reinterpret_cast<uint32_t*>(arena.base + o_sba); seg_e_alt.p = reinterpret_cast<uint32_t*>(arena.base + o_sea);
+    flags.p = reinterpret_cast<uint32_t*>(arena.base + o_flags); rank.p = reinterpret_cast<uint32_t*>(arena.base + o_rank); uniq.p = reinterpret_cast<uint32_t*>(arena.base + o_uniq);
+    best.p = reinterpret_cast<Cand*>(arena.base + o_best); best_seg.p = reinterpret_cast<Cand*>(arena.base + o_bests);
+    left.p = arena.base + o_left; temp.p = arena.base + o_temp;
+    ctl.p = reinterpret_cast<BuildCtl*>(arena.base + o_ctl); n_seg.p = reinterpret_cast<unsigned int*>(arena.base + o_nseg);
+
+    hipEvent_t ev0, ev1;
+    HIPS(hipEventCreate(&ev0));
+    if (hipEventCreate(&ev1) != hipSuccess) { (void)hipEventDestroy(ev0); return pt_fail(PT_ERR_DEVICE, "hipEventCreate"); }
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{ev0, ev1};
+
+    HIPS(hipEventRecord(ev0, nullptr));
+    for (int a = 0; a < 3; a++) {
+        hipLaunchKernelGGL(sort_keys_kernel, dim3(G), dim3(T), 0, nullptr, boxes.p, n, a, keys.p);
+        size_t tb = t_bytes;
+        HIPS(rocprim::radix_sort_keys(temp.p, tb, keys.p, keys_alt.p, (size_t)n, 0, 64, nullptr));
+        hipLaunchKernelGGL(gather_order_kernel, dim3(G), dim3(T), 0, nullptr, keys_alt.p, boxes.p, n, idx[a].p, bx[a].p);
+    }
+    hipLaunchKernelGGL(init_segments_kernel, dim3(G), dim3(T), 0, nullptr, n, seg_b.p, seg_e.p, slot.p);
+    HIPS(hipMemsetAsync(left.p, 0, (size_t)n, nullptr));
+    HIPS(hipGetLastError());
+
+    SB* cur_bx[3] = {bx[0].p, bx[1].p, bx[2].p};
+    SB* alt_bx[3] = {bx_alt[0].p, bx_alt[1].p, bx_alt[2].p};
+    int32_t* cur_idx[3] = {idx[0].p, idx[1].p, idx[2].p};
+    int32_t* alt_idx[3] = {idx_alt[0].p, idx_alt[1].p, idx_alt[2].p};
+    uint32_t *cur_b = seg_b.p, *cur_e = seg_e.p, *alt_b = seg_b_alt.p, *alt_e = seg_e_alt.p;
+    BuildCtl h{};
+    int depth = 1;
+    for (;; depth++) {
+        if (depth > guard_depth + 2) return pt_fail(PT_ERR_UNSUPPORTED, "sweep_build_device: deeper than the host builder's guard");
+        for (int a = 0; a < 3; a++) {
+            size_t tb = t_bytes;
+            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, cur_bx[a], pre.p, (size_t)n, MergeKeepFirst(),
+                                                rocprim::equal_to<uint32_t>(), nullptr));
+            auto kr = rocprim::make_reverse_iterator(cur_b + n);
+            auto vr = rocprim::make_reverse_iterator(cur_bx[a] + n);
+            auto orr = rocprim::make_reverse_iterator(suf.p + n);
+            tb = t_bytes;
+            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, kr, vr, orr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
+            hipLaunchKernelGGL(cand_kernel, dim3(G), dim3(T), 0, nullptr, pre.p, suf.p, cur_b, cur_e, n, a, best.p, whole.p);
+        }
+        size_t tb = t_bytes;
+        HIPS(rocprim::reduce_by_key(temp.p, tb, cur_b, best.p, (size_t)n, uniq.p, best_seg.p, n_seg.p, CandMin(),
+                                    rocprim::equal_to<uint32_t>(), nullptr));
+        HIPS(hipMemsetAsync(ctl.p, 0, sizeof(unsigned int) * 2, nullptr));           // active, too_deep (max_depth stays)
+        if (depth == 1) HIPS(hipMemsetAsync(ctl.p, 0, sizeof(BuildCtl), nullptr));
+        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, uniq.p, best_seg.p, n_seg.p, cur_e, whole.p, cur_idx[0], cur_bx[0],
+                           slot.p, split.p, nodes.p, depth, guard_depth, ctl.p);
+        HIPS(hipGetLastError());
+        HIPS(hipMemcpy(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost));
+        if (h.too_deep) return pt_fail(PT_ERR_UNSUPPORTED, "sweep_build_device: a branch beyond the depth guard (host builder takes over)");
+        if (h.active == 0) break;
+        hipLaunchKernelGGL(mark_left_kernel, dim3(G), dim3(T), 0, nullptr, cur_b, split.p, cur_idx[0], cur_idx[1], cur_idx[2], n, left.p);
+        for (int a = 0; a < 3; a++) {
+            hipLaunchKernelGGL(flags_kernel, dim3(G), dim3(T), 0, nullptr, cur_idx[a], left.p, n, flags.p);
+            tb = t_bytes;
+            HIPS(rocprim::exclusive_scan_by_key(temp.p, tb, cur_b, flags.p, rank.p, 0u, (size_t)n, rocprim::plus<uint32_t>(),
+                                                rocprim::equal_to<uint32_t>(), nullptr));
+            hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(T), 0, nullptr, cur_idx[a], cur_bx[a], flags.p, rank.p, cur_b, cur_e, split.p, n,
+                               alt_idx[a], alt_bx[a], a == 0 ? alt_b : (uint32_t*)nullptr, a == 0 ? alt_e : (uint32_t*)nullptr);
+        }
+        HIPS(hipMemsetAsync(left.p, 0, (size_t)n, nullptr));
+        HIPS(hipGetLastError());
+        for (int a = 0; a < 3; a++) { std::swap(cur_bx[a], alt_bx[a]); std::swap(cur_idx[a], alt_idx[a]); }
+        std::swap(cur_b, alt_b);
+        std::swap(cur_e, alt_e);
+    }
+    HIPS(hipEventRecord(ev1, nullptr));
+    HIPS(hipEventSynchronize(ev1));
+    float ms = 0;
+    HIPS(hipEventElapsedTime(&ms, ev0, ev1));
+    if (out_device_ms) *out_device_ms = ms;
+    if (out_depth) *out_depth = h.max_depth;
+    return PT_OK;
+}

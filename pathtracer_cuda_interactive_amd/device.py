@@ -16,7 +16,7 @@ _lib = None
 EXPORTS = [
     "pt_api_version", "pt_last_error", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_async",
     "pt_render_accumulate", "pt_get_counters", "pt_scene_set_option", "pt_scene_get_info", "pt_debug_math",
-    "pt_debug_intersect", "pt_debug_math_host", "pt_bvh_build_device", "pt_bvh_build_sweep", "pt_get_frame_times",
+    "pt_debug_intersect", "pt_debug_math_host", "pt_bvh_build_device", "pt_bvh_build_sweep", "pt_get_frame_times", "pt_bvh_build_sweep_device",
 ]
 
 
@@ -46,6 +46,7 @@ def lib():
         L.pt_debug_math_host.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int]
         L.pt_bvh_build_device.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(PtBvhNode), ip, ip, C.POINTER(C.c_double)]
         L.pt_bvh_build_sweep.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtBvhNode), ip, ip, C.POINTER(C.c_double)]
+        L.pt_bvh_build_sweep_device.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtBvhNode), ip, ip, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -138,13 +139,14 @@ def debug_math(op, x, y=None, host=False):
     return o0, o1
 
 
-def build_bvh_sweep(desc):
-    """The library's internal-tree builder (pt_bvh_build_sweep: host code, runs without a GPU) over the leaf boxes of
-    `desc`'s tree.  Returns (desc2, info) like build_bvh_device."""
+def build_bvh_sweep(desc, on_device=False):
+    """The library's internal-tree builder over the leaf boxes of `desc`'s tree: pt_bvh_build_sweep (host code, runs without a
+    GPU) or, on_device=True, pt_bvh_build_sweep_device — the same tree byte for byte.  Returns (desc2, info) like build_bvh_device."""
     n_nodes = 2 * desc.num_shapes - 1
     nodes = np.zeros(max(n_nodes, 1), dtype=NODE_DTYPE)
     root, depth, ms = C.c_int32(), C.c_int32(), C.c_double()
-    _check(lib().pt_bvh_build_sweep(C.byref(desc), nodes.ctypes.data_as(C.POINTER(PtBvhNode)), C.byref(root), C.byref(depth),
+    fn = lib().pt_bvh_build_sweep_device if on_device else lib().pt_bvh_build_sweep
+    _check(fn(C.byref(desc), nodes.ctypes.data_as(C.POINTER(PtBvhNode)), C.byref(root), C.byref(depth),
                                     C.byref(ms)))
     d2 = PtSceneDesc()
     C.memmove(C.byref(d2), C.byref(desc), C.sizeof(PtSceneDesc))
