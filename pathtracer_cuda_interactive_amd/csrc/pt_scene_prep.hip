@@ -281,12 +281,25 @@ int ptp::relay_tree_device(const pt_bvh_node* pool_dev, int num_nodes, int root,
         return pt_fail(PT_ERR_INVALID_ARG, "relay_tree_device: bad argument");
     const int T = 256, G = (num_nodes + T - 1) / T;
     const bool validate = !internal;
-    TmpBuf<int32_t> parent, level, leaves, need, pre, top, top_sorted, top_rank, n_top_dev;
-    TmpBuf<unsigned int> refs, prim_refs;
-    TmpBuf<RelayCtl> ctl;
-    HIPP(parent.alloc(num_nodes)); HIPP(level.alloc(num_nodes)); HIPP(leaves.alloc(num_nodes)); HIPP(need.alloc(num_nodes));
-    HIPP(pre.alloc(num_nodes)); HIPP(top.alloc(top_nodes_max)); HIPP(top_sorted.alloc(top_nodes_max)); HIPP(top_rank.alloc(top_nodes_max));
-    HIPP(n_top_dev.alloc(1)); HIPP(refs.alloc(validate ? num_nodes : 1)); HIPP(prim_refs.alloc(validate ? N : 1)); HIPP(ctl.alloc(1));
+    // one allocation for the working arrays (a hipMalloc / hipFree pair each would cost as much as the kernels)
+    struct { int32_t* p; } parent, level, leaves, need, pre, top, top_sorted, top_rank, n_top_dev;
+    struct { unsigned int* p; } refs, prim_refs;
+    struct { RelayCtl* p; } ctl;
+    TmpBuf<unsigned char> arena;
+    {
+        size_t used = 0;
+        auto take = [&used](size_t bytes) { const size_t at = used; used += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t nn = (size_t)num_nodes;
+        const size_t o_parent = take(nn * 4), o_level = take(nn * 4), o_leaves = take(nn * 4), o_need = take(nn * 4), o_pre = take(nn * 4);
+        const size_t o_top = take((size_t)top_nodes_max * 4), o_tops = take((size_t)top_nodes_max * 4), o_topr = take((size_t)top_nodes_max * 4), o_ntop = take(4);
+        const size_t o_refs = take(validate ? nn * 4 : 4), o_prefs = take(validate ? (size_t)N * 4 : 4), o_ctl = take(sizeof(RelayCtl));
+        HIPP(arena.alloc(used));
+        unsigned char* b = arena.p;
+        parent.p = reinterpret_cast<int32_t*>(b + o_parent); level.p = reinterpret_cast<int32_t*>(b + o_level); leaves.p = reinterpret_cast<int32_t*>(b + o_leaves);
+        need.p = reinterpret_cast<int32_t*>(b + o_need); pre.p = reinterpret_cast<int32_t*>(b + o_pre); top.p = reinterpret_cast<int32_t*>(b + o_top);
+        top_sorted.p = reinterpret_cast<int32_t*>(b + o_tops); top_rank.p = reinterpret_cast<int32_t*>(b + o_topr); n_top_dev.p = reinterpret_cast<int32_t*>(b + o_ntop);
+        refs.p = reinterpret_cast<unsigned int*>(b + o_refs); prim_refs.p = reinterpret_cast<unsigned int*>(b + o_prefs); ctl.p = reinterpret_cast<RelayCtl*>(b + o_ctl);
+    }
     HIPP(hipMemsetAsync(ctl.p, 0, sizeof(RelayCtl), nullptr));
     HIPP(hipMemsetAsync(parent.p, 0xff, (size_t)num_nodes * sizeof(int32_t), nullptr));        // "no parent": the walk never leaves the array
     if (validate) {

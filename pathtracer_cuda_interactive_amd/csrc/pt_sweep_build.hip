@@ -136,6 +136,79 @@ __global__ void cand_kernel(const SB* __restrict__ pre, const SB* __restrict__ s
     best[i] = axis == 0 ? c : CandMin()(best[i], c);
 }
 
+// The three orders side by side: element i = position i of the x-, y- and z-order.  All three share their node ranges, so one
+// segmented scan over triples does the work of three (a third of the launches; the levels of a build are launch-bound).
+struct SB3 { SB* a[3]; };        // the boxes of the three orders: one array per order (24-B elements scan faster than 72-B ones)
+struct I3 { int32_t a[3]; };
+struct U3 { uint32_t a[3]; };
+struct Plus3 {
+    __host__ __device__ U3 operator()(const U3& x, const U3& y) const { return U3{{x.a[0] + y.a[0], x.a[1] + y.a[1], x.a[2] + y.a[2]}}; }
+};
+
+__global__ void gather_order3_kernel(const unsigned long long* __restrict__ keys, const SB* __restrict__ boxes, int n, int axis,
+                                     I3* __restrict__ idx, SB* __restrict__ bx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = (int32_t)(uint32_t)keys[i];
+    idx[i].a[axis] = p;
+    bx[i] = boxes[p];
+}
+// best cut after position i over the three axes (cand_kernel for all of them); the node's box at its first position
+__global__ void cand3_kernel(const SB3 pre, const SB3 suf, const uint32_t* __restrict__ seg_b,
+                             const uint32_t* __restrict__ seg_e, int n, Cand* __restrict__ best, SB* __restrict__ whole) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = seg_b[i], e = seg_e[i];
+    if ((uint32_t)i == b) whole[b] = clamp_like_host(suf.a[0][i]);
+    Cand c = cand_none();
+    if ((uint32_t)i + 1 < e) {
+        const int k = i - (int)b + 1, m = (int)(e - b);
+        const int off = 2 * k > m ? 2 * k - m : m - 2 * k;
+        for (int a = 0; a < 3; a++) {
+            Cand t;
+            t.cost = area_like_host(clamp_like_host(pre.a[a][i])) * k + area_like_host(clamp_like_host(suf.a[a][i + 1])) * (m - k);
+            t.off = off;
+            t.ak = (a << 28) | k;
+            c = a == 0 ? t : CandMin()(c, t);
+        }
+    }
+    best[i] = c;
+}
+__global__ void mark_left3_kernel(const uint32_t* __restrict__ seg_b, const int32_t* __restrict__ split, const I3* __restrict__ idx, int n,
+                                  unsigned char* __restrict__ left) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = seg_b[i];
+    const int32_t sp = split[b];
+    const int axis = sp >> 28, k = sp & 0x0fffffff;
+    if (i - (int)b < k) left[idx[i].a[axis]] = 1;
+}
+__global__ void flags3_kernel(const I3* __restrict__ idx, const unsigned char* __restrict__ left, int n, U3* __restrict__ f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const I3 v = idx[i];
+    f[i] = U3{{left[v.a[0]], left[v.a[1]], left[v.a[2]]}};
+}
+__global__ void scatter3_kernel(const I3* __restrict__ idx, const SB3 bx, const U3* __restrict__ f, const U3* __restrict__ rank,
+                                const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e, const int32_t* __restrict__ split, int n,
+                                I3* __restrict__ idx_out, const SB3 bx_out, uint32_t* __restrict__ seg_b_out,
+                                uint32_t* __restrict__ seg_e_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = seg_b[i], e = seg_e[i];
+    const uint32_t k = (uint32_t)(split[b] & 0x0fffffff);
+    const U3 fl = f[i], r = rank[i];
+    for (int a = 0; a < 3; a++) {
+        const uint32_t dest = fl.a[a] ? b + r.a[a] : b + k + ((uint32_t)i - b - r.a[a]);
+        idx_out[dest].a[a] = idx[i].a[a];
+        bx_out.a[a][dest] = bx.a[a][i];
+        if (a == 0) {
+            seg_b_out[dest] = fl.a[0] ? b : b + k;
+            seg_e_out[dest] = fl.a[0] ? b + k : e;
+        }
+    }
+}
+// apply_kernel's view of the x-order
 struct BuildCtl {
     unsigned int active;        // nodes of the next level with more than one primitive
     unsigned int too_deep;      // a node beyond the host builder's depth guard: hand the build back
@@ -145,7 +218,7 @@ struct BuildCtl {
 
 // One thread per node of the level (the reduction's output j): emit it, split it.
 __global__ void apply_kernel(const uint32_t* __restrict__ uniq_b, const Cand* __restrict__ best, const unsigned int* __restrict__ n_seg,
-                             const uint32_t* __restrict__ seg_e, const SB* __restrict__ whole, const int32_t* __restrict__ idx0,
+                             const uint32_t* __restrict__ seg_e, const SB* __restrict__ whole, const I3* __restrict__ idx3,
                              const SB* __restrict__ bx0, int32_t* __restrict__ slot, int32_t* __restrict__ split,
                              pt_bvh_node* __restrict__ out, int depth, int guard_depth, BuildCtl* __restrict__ ctl) {
     const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,7 +231,7 @@ __global__ void apply_kernel(const uint32_t* __restrict__ uniq_b, const Cand* __
         if (s >= 0) {                                   // a leaf not written yet
             pt_bvh_node nd;
             for (int k = 0; k < 3; k++) { nd.bmin[k] = bx0[b].lo[k]; nd.bmax[k] = bx0[b].hi[k]; }
-            nd.left = -1; nd.right = -1; nd.prim = idx0[b];
+            nd.left = -1; nd.right = -1; nd.prim = idx3[b].a[0];
             out[s] = nd;
             slot[b] = -1;
             atomicMax(&ctl->max_depth, depth);
@@ -267,10 +340,13 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
         ~Arena() { if (base) (void)hipFree(base); }
         size_t reserve(size_t bytes) { const size_t at = used; used += (bytes + 255) & ~(size_t)255; return at; }
     } arena;
-    struct { SB* p; } bx[3], bx_alt[3], pre, suf, whole;
-    struct { int32_t* p; } idx[3], idx_alt[3], slot, split;
+    SB3 bx{}, bx_alt{}, pre{}, suf{};
+    struct { SB* p; } whole;
+    struct { I3* p; } idx, idx_alt;
+    struct { int32_t* p; } slot, split;
     struct { unsigned long long* p; } keys, keys_alt;
-    struct { uint32_t* p; } seg_b, seg_e, seg_b_alt, seg_e_alt, flags, rank, uniq;
+    struct { uint32_t* p; } seg_b, seg_e, seg_b_alt, seg_e_alt, uniq;
+    struct { U3* p; } flags, rank;
     struct { Cand* p; } best, best_seg;
     struct { unsigned char* p; } left, temp;
     struct { BuildCtl* p; } ctl;
@@ -278,36 +354,37 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     // temporary storage of the rocPRIM calls: the largest of the five kinds, sized once (size queries read no memory)
     size_t t_sort = 0, t_scan_box = 0, t_scan_box_r = 0, t_scan_u = 0, t_reduce = 0;
     {
-        unsigned long long* k64 = nullptr; uint32_t* k32 = nullptr; SB* sb = nullptr; Cand* cd = nullptr; unsigned int* cnt = nullptr;
+        unsigned long long* k64 = nullptr; uint32_t* k32 = nullptr; SB* sb = nullptr; Cand* cd = nullptr; unsigned int* cnt = nullptr; U3* u3 = nullptr;
         HIPS(rocprim::radix_sort_keys(nullptr, t_sort, k64, k64, (size_t)n, 0, 64, nullptr));
         HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box, k32, sb, sb, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
         auto kr = rocprim::make_reverse_iterator(k32 + n);
         auto vr = rocprim::make_reverse_iterator(sb + n);
         HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box_r, kr, vr, vr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
-        HIPS(rocprim::exclusive_scan_by_key(nullptr, t_scan_u, k32, k32, k32, 0u, (size_t)n, rocprim::plus<uint32_t>(), rocprim::equal_to<uint32_t>(), nullptr));
+        HIPS(rocprim::exclusive_scan_by_key(nullptr, t_scan_u, k32, u3, u3, U3{{0u, 0u, 0u}}, (size_t)n, Plus3(), rocprim::equal_to<uint32_t>(), nullptr));
         HIPS(rocprim::reduce_by_key(nullptr, t_reduce, k32, cd, (size_t)n, k32, cd, cnt, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
     }
     const size_t t_bytes = std::max(std::max(std::max(t_sort, t_scan_box), std::max(t_scan_box_r, t_scan_u)), t_reduce);
     const size_t nn = (size_t)n;
-    size_t o_bx[3], o_bxa[3], o_idx[3], o_idxa[3];
-    for (int a = 0; a < 3; a++) { o_bx[a] = arena.reserve(nn * sizeof(SB)); o_bxa[a] = arena.reserve(nn * sizeof(SB)); o_idx[a] = arena.reserve(nn * 4); o_idxa[a] = arena.reserve(nn * 4); }
-    const size_t o_pre = arena.reserve(nn * sizeof(SB)), o_suf = arena.reserve(nn * sizeof(SB)), o_whole = arena.reserve(nn * sizeof(SB));
+    size_t o_bx[3], o_bxa[3], o_pre[3], o_suf[3];
+    for (int a = 0; a < 3; a++) { o_bx[a] = arena.reserve(nn * sizeof(SB)); o_bxa[a] = arena.reserve(nn * sizeof(SB)); o_pre[a] = arena.reserve(nn * sizeof(SB)); o_suf[a] = arena.reserve(nn * sizeof(SB)); }
+    const size_t o_idx = arena.reserve(nn * sizeof(I3)), o_idxa = arena.reserve(nn * sizeof(I3)), o_whole = arena.reserve(nn * sizeof(SB));
     const size_t o_slot = arena.reserve(nn * 4), o_split = arena.reserve(nn * 4), o_keys = arena.reserve(nn * 8), o_keysa = arena.reserve(nn * 8);
     const size_t o_sb = arena.reserve(nn * 4), o_se = arena.reserve(nn * 4), o_sba = arena.reserve(nn * 4), o_sea = arena.reserve(nn * 4);
-    const size_t o_flags = arena.reserve(nn * 4), o_rank = arena.reserve(nn * 4), o_uniq = arena.reserve(nn * 4);
+    const size_t o_flags = arena.reserve(nn * sizeof(U3)), o_rank = arena.reserve(nn * sizeof(U3)), o_uniq = arena.reserve(nn * 4);
     const size_t o_best = arena.reserve(nn * sizeof(Cand)), o_bests = arena.reserve(nn * sizeof(Cand)), o_left = arena.reserve(nn);
     const size_t o_ctl = arena.reserve(sizeof(BuildCtl)), o_nseg = arena.reserve(sizeof(unsigned int)), o_temp = arena.reserve(t_bytes);
     HIPS(hipMalloc(reinterpret_cast<void**>(&arena.base), arena.used));
     for (int a = 0; a < 3; a++) {
-        bx[a].p = reinterpret_cast<SB*>(arena.base + o_bx[a]); bx_alt[a].p = reinterpret_cast<SB*>(arena.base + o_bxa[a]);
-        idx[a].p = reinterpret_cast<int32_t*>(arena.base + o_idx[a]); idx_alt[a].p = reinterpret_cast<int32_t*>(arena.base + o_idxa[a]);
+        bx.a[a] = reinterpret_cast<SB*>(arena.base + o_bx[a]); bx_alt.a[a] = reinterpret_cast<SB*>(arena.base + o_bxa[a]);
+        pre.a[a] = reinterpret_cast<SB*>(arena.base + o_pre[a]); suf.a[a] = reinterpret_cast<SB*>(arena.base + o_suf[a]);
     }
-    pre.p = reinterpret_cast<SB*>(arena.base + o_pre); suf.p = reinterpret_cast<SB*>(arena.base + o_suf); whole.p = reinterpret_cast<SB*>(arena.base + o_whole);
+    idx.p = reinterpret_cast<I3*>(arena.base + o_idx); idx_alt.p = reinterpret_cast<I3*>(arena.base + o_idxa);
+    whole.p = reinterpret_cast<SB*>(arena.base + o_whole);
     slot.p = reinterpret_cast<int32_t*>(arena.base + o_slot); split.p = reinterpret_cast<int32_t*>(arena.base + o_split);
     keys.p = reinterpret_cast<unsigned long long*>(arena.base + o_keys); keys_alt.p = reinterpret_cast<unsigned long long*>(arena.base + o_keysa);
     seg_b.p = reinterpret_cast<uint32_t*>(arena.base + o_sb); seg_e.p = reinterpret_cast<uint32_t*>(arena.base + o_se);
     seg_b_alt.p = reinterpret_cast<uint32_t*>(arena.base + o_sba); seg_e_alt.p = reinterpret_cast<uint32_t*>(arena.base + o_sea);
-    flags.p = reinterpret_cast<uint32_t*>(arena.base + o_flags); rank.p = reinterpret_cast<uint32_t*>(arena.base + o_rank); uniq.p = reinterpret_cast<uint32_t*>(arena.base + o_uniq);
+    flags.p = reinterpret_cast<U3*>(arena.base + o_flags); rank.p = reinterpret_cast<U3*>(arena.base + o_rank); uniq.p = reinterpret_cast<uint32_t*>(arena.base + o_uniq);
     best.p = reinterpret_cast<Cand*>(arena.base + o_best); best_seg.p = reinterpret_cast<Cand*>(arena.base + o_bests);
     left.p = arena.base + o_left; temp.p = arena.base + o_temp;
     ctl.p = reinterpret_cast<BuildCtl*>(arena.base + o_ctl); n_seg.p = reinterpret_cast<unsigned int*>(arena.base + o_nseg);
@@ -322,55 +399,51 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
         hipLaunchKernelGGL(sort_keys_kernel, dim3(G), dim3(T), 0, nullptr, boxes.p, n, a, keys.p);
         size_t tb = t_bytes;
         HIPS(rocprim::radix_sort_keys(temp.p, tb, keys.p, keys_alt.p, (size_t)n, 0, 64, nullptr));
-        hipLaunchKernelGGL(gather_order_kernel, dim3(G), dim3(T), 0, nullptr, keys_alt.p, boxes.p, n, idx[a].p, bx[a].p);
+        hipLaunchKernelGGL(gather_order3_kernel, dim3(G), dim3(T), 0, nullptr, keys_alt.p, boxes.p, n, a, idx.p, bx.a[a]);
     }
     hipLaunchKernelGGL(init_segments_kernel, dim3(G), dim3(T), 0, nullptr, n, seg_b.p, seg_e.p, slot.p);
     HIPS(hipMemsetAsync(left.p, 0, (size_t)n, nullptr));
+    HIPS(hipMemsetAsync(ctl.p, 0, sizeof(BuildCtl), nullptr));
     HIPS(hipGetLastError());
 
-    SB* cur_bx[3] = {bx[0].p, bx[1].p, bx[2].p};
-    SB* alt_bx[3] = {bx_alt[0].p, bx_alt[1].p, bx_alt[2].p};
-    int32_t* cur_idx[3] = {idx[0].p, idx[1].p, idx[2].p};
-    int32_t* alt_idx[3] = {idx_alt[0].p, idx_alt[1].p, idx_alt[2].p};
+    SB3 cur_bx = bx, alt_bx = bx_alt;
+    I3 *cur_idx = idx.p, *alt_idx = idx_alt.p;
     uint32_t *cur_b = seg_b.p, *cur_e = seg_e.p, *alt_b = seg_b_alt.p, *alt_e = seg_e_alt.p;
     BuildCtl h{};
     int depth = 1;
     for (;; depth++) {
         if (depth > guard_depth + 2) return pt_fail(PT_ERR_UNSUPPORTED, "sweep_build_device: deeper than the host builder's guard");
+        size_t tb = t_bytes;
         for (int a = 0; a < 3; a++) {
-            size_t tb = t_bytes;
-            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, cur_bx[a], pre.p, (size_t)n, MergeKeepFirst(),
-                                                rocprim::equal_to<uint32_t>(), nullptr));
+            tb = t_bytes;
+            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, cur_bx.a[a], pre.a[a], (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
             auto kr = rocprim::make_reverse_iterator(cur_b + n);
-            auto vr = rocprim::make_reverse_iterator(cur_bx[a] + n);
-            auto orr = rocprim::make_reverse_iterator(suf.p + n);
+            auto vr = rocprim::make_reverse_iterator(cur_bx.a[a] + n);
+            auto orr = rocprim::make_reverse_iterator(suf.a[a] + n);
             tb = t_bytes;
             HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, kr, vr, orr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
-            hipLaunchKernelGGL(cand_kernel, dim3(G), dim3(T), 0, nullptr, pre.p, suf.p, cur_b, cur_e, n, a, best.p, whole.p);
         }
-        size_t tb = t_bytes;
+        hipLaunchKernelGGL(cand3_kernel, dim3(G), dim3(T), 0, nullptr, pre, suf, cur_b, cur_e, n, best.p, whole.p);
+        tb = t_bytes;
         HIPS(rocprim::reduce_by_key(temp.p, tb, cur_b, best.p, (size_t)n, uniq.p, best_seg.p, n_seg.p, CandMin(),
                                     rocprim::equal_to<uint32_t>(), nullptr));
         HIPS(hipMemsetAsync(ctl.p, 0, sizeof(unsigned int) * 2, nullptr));           // active, too_deep (max_depth stays)
-        if (depth == 1) HIPS(hipMemsetAsync(ctl.p, 0, sizeof(BuildCtl), nullptr));
-        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, uniq.p, best_seg.p, n_seg.p, cur_e, whole.p, cur_idx[0], cur_bx[0],
+        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, uniq.p, best_seg.p, n_seg.p, cur_e, whole.p, cur_idx, cur_bx.a[0],
                            slot.p, split.p, nodes.p, depth, guard_depth, ctl.p);
         HIPS(hipGetLastError());
         HIPS(hipMemcpy(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost));
         if (h.too_deep) return pt_fail(PT_ERR_UNSUPPORTED, "sweep_build_device: a branch beyond the depth guard (host builder takes over)");
         if (h.active == 0) break;
-        hipLaunchKernelGGL(mark_left_kernel, dim3(G), dim3(T), 0, nullptr, cur_b, split.p, cur_idx[0], cur_idx[1], cur_idx[2], n, left.p);
-        for (int a = 0; a < 3; a++) {
-            hipLaunchKernelGGL(flags_kernel, dim3(G), dim3(T), 0, nullptr, cur_idx[a], left.p, n, flags.p);
-            tb = t_bytes;
-            HIPS(rocprim::exclusive_scan_by_key(temp.p, tb, cur_b, flags.p, rank.p, 0u, (size_t)n, rocprim::plus<uint32_t>(),
-                                                rocprim::equal_to<uint32_t>(), nullptr));
-            hipLaunchKernelGGL(scatter_kernel, dim3(G), dim3(T), 0, nullptr, cur_idx[a], cur_bx[a], flags.p, rank.p, cur_b, cur_e, split.p, n,
-                               alt_idx[a], alt_bx[a], a == 0 ? alt_b : (uint32_t*)nullptr, a == 0 ? alt_e : (uint32_t*)nullptr);
-        }
+        hipLaunchKernelGGL(mark_left3_kernel, dim3(G), dim3(T), 0, nullptr, cur_b, split.p, cur_idx, n, left.p);
+        hipLaunchKernelGGL(flags3_kernel, dim3(G), dim3(T), 0, nullptr, cur_idx, left.p, n, flags.p);
+        tb = t_bytes;
+        HIPS(rocprim::exclusive_scan_by_key(temp.p, tb, cur_b, flags.p, rank.p, U3{{0u, 0u, 0u}}, (size_t)n, Plus3(), rocprim::equal_to<uint32_t>(), nullptr));
+        hipLaunchKernelGGL(scatter3_kernel, dim3(G), dim3(T), 0, nullptr, cur_idx, cur_bx, flags.p, rank.p, cur_b, cur_e, split.p, n,
+                           alt_idx, alt_bx, alt_b, alt_e);
         HIPS(hipMemsetAsync(left.p, 0, (size_t)n, nullptr));
         HIPS(hipGetLastError());
-        for (int a = 0; a < 3; a++) { std::swap(cur_bx[a], alt_bx[a]); std::swap(cur_idx[a], alt_idx[a]); }
+        std::swap(cur_bx, alt_bx);
+        std::swap(cur_idx, alt_idx);
         std::swap(cur_b, alt_b);
         std::swap(cur_e, alt_e);
     }
