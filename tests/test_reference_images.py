@@ -86,15 +86,28 @@ def test_oracle_converges_to_the_reference_screenshot(oracle, name, flavour):
     compare(name, img, same_resolution=False)
 
 
+# GPU leg: the screenshot's own resolution at 8,192 spp — our own Monte-Carlo noise is then far below one display step per block
+# (cbox: 8.6 G paths, 1.5 s on one MI355X), and what is left in the residual is the reference's noise and its 8-bit quantisation.
+# Tolerances = 1.25 x the residuals measured at that sample count (profiles/r03_reference_image_residuals.log), per screenshot:
+#                 worst block (display steps)   rms over blocks   |mean| relative
+GPU_SPP = 8192
+GPU_TOL = {                                  # measured: worst / rms / |mean|        x 1.25
+    "bunny":        (0.62, 0.315, 0.0028),    # 0.494 / 0.251 / 0.22 %
+    "cbox":         (3.50, 0.275, 0.0020),    # 2.793 (a block on the light's edge; unsaturated blocks 1.07) / 0.220 / 0.15 %
+    "scene1_phong": (0.72, 0.390, 0.0043),    # 0.569 / 0.311 / 0.34 %
+    "scene4":       (0.61, 0.433, 0.0050),    # 0.488 / 0.346 / 0.39 %
+}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CPU_CASES))
 def test_device_converges_to_the_reference_screenshot(name):
-    """The HIP path at the screenshot's own resolution (1024x1024 / 1280x960) and 512 spp: every block, saturated or
-    not, within the tight tolerance, because the clamp now acts on the same pixel footprints as in the reference."""
+    """The HIP path at the screenshot's own resolution (1024x1024 / 1280x960 / 640x480): every block, saturated or not (the clamp
+    acts on the same pixel footprints as in the reference), within 1.25 x the residual measured at this sample count."""
     from pathtracer_cuda_interactive_amd import device as dev
     pin = PINS[name]
     hs, d = load_scene(pin["scene"])
-    p = hs.render_params(pin["width"], pin["height"], 512)
+    p = hs.render_params(pin["width"], pin["height"], GPU_SPP)
     ds = dev.DeviceScene(d)
     try:
         img = ds.render(p)
@@ -102,7 +115,11 @@ def test_device_converges_to_the_reference_screenshot(name):
         ds.close()
     assert (img[0, 0] == np.float32(0.25 if name == "bunny" else 0.5)).all()
     stats = compare(name, img, same_resolution=True)
-    print(name, stats)
+    print("RESIDUALS", name, GPU_SPP, "spp:", stats)
+    tol_block, tol_rms, tol_mean = GPU_TOL[name]
+    if tol_block is not None:
+        assert stats["worst_all"] <= tol_block and stats["rms_unsat"] <= tol_rms, (name, stats)
+        assert max(abs(v) for v in stats["global_rel"]) <= tol_mean, (name, stats)
 
 
 # ---- can the pin fail?  Mutation tests (oracle-side, test-only switches: oracle/pt_oracle.h pt_oracle_set_mutation) -------------
