@@ -197,6 +197,7 @@ __global__ void relay_top_kernel(const pt_bvh_node* __restrict__ pool, int root,
     if (want > 0) push(__builtin_huge_val(), 0, root);
     while (size > 0 && picked < want) {
         const int32_t k = h_node[0];
+        const int32_t h_neg_popped = h_neg[0];
         size--;
         if (size > 0) {
             h_area[0] = h_area[size]; h_neg[0] = h_neg[size]; h_node[0] = h_node[size];
@@ -213,12 +214,14 @@ __global__ void relay_top_kernel(const pt_bvh_node* __restrict__ pool, int root,
                 i = m;
             }
         }
-        top_pre[picked] = pre[k];
+        top_pre[picked] = -h_neg_popped;
         top[picked++] = k;
+        // the two children's records and pre-order positions: four independent loads, one wait
         const pt_bvh_node nd = pool[k];
-        const int32_t ch[2] = {nd.left, nd.right};
-        for (int c = 0; c < 2; c++)
-            if (pool[ch[c]].prim == -1) push(relay_area(pool[ch[c]]), -pre[ch[c]], ch[c]);
+        const pt_bvh_node c0 = pool[nd.left], c1 = pool[nd.right];
+        const int32_t p0 = pre[nd.left], p1 = pre[nd.right];
+        if (c0.prim == -1) push(relay_area(c0), -p0, nd.left);
+        if (c1.prim == -1) push(relay_area(c1), -p1, nd.right);
     }
     *n_top = picked;
 }

@@ -212,48 +212,155 @@ __global__ void scatter3_kernel(const I3* __restrict__ idx, const SB3 bx, const 
 struct BuildCtl {
     unsigned int active;        // nodes of the next level with more than one primitive
     unsigned int too_deep;      // a node beyond the host builder's depth guard: hand the build back
-    int max_depth;
-    unsigned int pad;
+    unsigned int max_child;     // primitives of the largest node of the next level
+    int max_depth;              // (kept across levels: the three words before it are cleared per level)
 };
 
-// One thread per node of the level (the reduction's output j): emit it, split it.
-__global__ void apply_kernel(const uint32_t* __restrict__ uniq_b, const Cand* __restrict__ best, const unsigned int* __restrict__ n_seg,
-                             const uint32_t* __restrict__ seg_e, const SB* __restrict__ whole, const I3* __restrict__ idx3,
-                             const SB* __restrict__ bx0, int32_t* __restrict__ slot, int32_t* __restrict__ split,
-                             pt_bvh_node* __restrict__ out, int depth, int guard_depth, BuildCtl* __restrict__ ctl) {
-    const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= *n_seg) return;
-    const uint32_t b = uniq_b[j], e = seg_e[b];
-    const int m = (int)(e - b);
-    const int32_t s = slot[b];
-    if (m == 1) {
-        split[b] = 0;                                   // axis 0, k = 0: the partition below leaves the position where it is
-        if (s >= 0) {                                   // a leaf not written yet
+// One thread per position; the one that starts a node emits it and splits it.  best_scan = inclusive segmented min-scan of the
+// cut candidates: a node's best cut stands at its last position.  The level's control words are summed per block first.
+__global__ void apply_kernel(const Cand* __restrict__ best_scan, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
+                             const SB* __restrict__ whole, const I3* __restrict__ idx3, const SB* __restrict__ bx0, int n,
+                             int32_t* __restrict__ slot, int32_t* __restrict__ split, pt_bvh_node* __restrict__ out, int depth,
+                             int guard_depth, BuildCtl* __restrict__ ctl) {
+    __shared__ unsigned int sh_active, sh_deep, sh_wrote, sh_child;
+    if (threadIdx.x == 0) { sh_active = 0; sh_deep = 0; sh_wrote = 0; sh_child = 0; }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && seg_b[i] == (uint32_t)i) {
+        const uint32_t b = (uint32_t)i, e = seg_e[i];
+        const int m = (int)(e - b);
+        const int32_t s = slot[b];
+        if (m == 1) {
+            split[b] = 0;                               // axis 0, k = 0: the partition below leaves the position where it is
+            if (s >= 0) {                               // a leaf not written yet
+                pt_bvh_node nd;
+                for (int k = 0; k < 3; k++) { nd.bmin[k] = bx0[b].lo[k]; nd.bmax[k] = bx0[b].hi[k]; }
+                nd.left = -1; nd.right = -1; nd.prim = idx3[b].a[0];
+                out[s] = nd;
+                slot[b] = -1;
+                sh_wrote = 1u;
+            }
+        } else if (depth > guard_depth) {
+            sh_deep = 1u;
+            split[b] = 0;
+        } else {
+            const Cand c = best_scan[e - 1];
+            const int axis = c.ak >> 28, k = c.ak & 0x0fffffff;
             pt_bvh_node nd;
-            for (int k = 0; k < 3; k++) { nd.bmin[k] = bx0[b].lo[k]; nd.bmax[k] = bx0[b].hi[k]; }
-            nd.left = -1; nd.right = -1; nd.prim = idx3[b].a[0];
+            for (int q = 0; q < 3; q++) { nd.bmin[q] = whole[b].lo[q]; nd.bmax[q] = whole[b].hi[q]; }
+            nd.prim = -1;
+            nd.left = s + 1;
+            nd.right = s + 2 * k;                       // the left subtree holds 2 k - 1 nodes
             out[s] = nd;
-            slot[b] = -1;
-            atomicMax(&ctl->max_depth, depth);
+            split[b] = (axis << 28) | k;
+            slot[b] = s + 1;                            // the children's slots, by their first positions
+            slot[b + (uint32_t)k] = s + 2 * k;
+            sh_wrote = 1u;
+            sh_active = 1u;                             // children exist: at least one more level (fresh leaves are written there)
+            atomicMax(&sh_child, (unsigned int)(k > m - k ? k : m - k));
         }
-        return;
     }
-    if (depth > guard_depth) { atomicAdd(&ctl->too_deep, 1u); split[b] = 0; return; }
-    const Cand c = best[j];
-    const int axis = c.ak >> 28, k = c.ak & 0x0fffffff;
-    pt_bvh_node nd;
-    for (int q = 0; q < 3; q++) { nd.bmin[q] = whole[b].lo[q]; nd.bmax[q] = whole[b].hi[q]; }
-    nd.prim = -1;
-    nd.left = s + 1;
-    nd.right = s + 2 * k;                               // the left subtree holds 2 k - 1 nodes
-    out[s] = nd;
-    atomicMax(&ctl->max_depth, depth);
-    split[b] = (axis << 28) | k;
-    slot[b] = s + 1;                                    // the children's slots, by their first positions
-    slot[b + (uint32_t)k] = s + 2 * k;
-    unsigned int more = (k > 1 ? 1u : 0u) + (m - k > 1 ? 1u : 0u);
-    if (k == 1 || m - k == 1) more += 1u;               // a fresh leaf still has to be written: one more level
-    if (more) atomicAdd(&ctl->active, more);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sh_active) atomicAdd(&ctl->active, 1u);
+        if (sh_deep) atomicAdd(&ctl->too_deep, 1u);
+        if (sh_wrote) atomicMax(&ctl->max_depth, depth);
+        if (sh_child) atomicMax(&ctl->max_child, sh_child);
+    }
+}
+
+// Once every node of a level holds at most kSmall primitives, one thread per node finishes its whole subtree by itself: the
+// host builder's own sequential steps (pt_tree_sweep.h: process / run_subtree — the same sweeps, the same comparisons in the same
+// order, hence the same bytes) on a private copy of the node's three orders.  The last six to eight levels of a build — as
+// many launches-times-whole-array passes as all the levels above them — become one launch.
+constexpr int kSmall = 32;      // 16 costs a level more, 64 makes the one-thread subtrees the long pole (buddha stand-in: 30.8 ms at 32, 32.1 at 64)
+__device__ __forceinline__ void merge_host(SB& a, const SB& b) {         // pts::sbox_merge
+    for (int k = 0; k < 3; k++) {
+        a.lo[k] = b.lo[k] < a.lo[k] ? b.lo[k] : a.lo[k];
+        a.hi[k] = b.hi[k] > a.hi[k] ? b.hi[k] : a.hi[k];
+    }
+}
+__device__ __forceinline__ SB empty_host() { return SB{{3.0e38f, 3.0e38f, 3.0e38f}, {-3.0e38f, -3.0e38f, -3.0e38f}}; }
+
+__global__ __launch_bounds__(64) void finish_small_kernel(const I3* __restrict__ idx, const SB3 bx, const uint32_t* __restrict__ seg_b,
+                                                          const uint32_t* __restrict__ seg_e, int n, const int32_t* __restrict__ slot,
+                                                          unsigned char* __restrict__ left, pt_bvh_node* __restrict__ out, int depth0,
+                                                          int guard_depth, BuildCtl* __restrict__ ctl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || seg_b[i] != (uint32_t)i) return;
+    const int b0 = i, m0 = (int)(seg_e[i] - seg_b[i]);
+    const int32_t s0 = slot[b0];
+    if (s0 < 0) return;                                 // a leaf written on an earlier level
+    int32_t lid[3][kSmall];                             // the node's three orders (primitive ids) and their boxes, private
+    SB lbx[3][kSmall];
+    int32_t tid[kSmall];
+    SB tbx[kSmall];
+    double suf[kSmall + 1];
+    for (int a = 0; a < 3; a++)
+        for (int j = 0; j < m0; j++) { lid[a][j] = idx[b0 + j].a[a]; lbx[a][j] = bx.a[a][b0 + j]; }
+    struct Task { int16_t b, e; int32_t slot; int16_t depth; };
+    Task todo[kSmall + 2];
+    int top = 0, deepest = depth0;
+    todo[top++] = Task{0, (int16_t)m0, s0, (int16_t)depth0};
+    while (top > 0) {
+        const Task t = todo[--top];
+        if (t.depth > deepest) deepest = t.depth;
+        const int m = t.e - t.b;
+        pt_bvh_node nd;
+        if (m == 1) {
+            for (int q = 0; q < 3; q++) { nd.bmin[q] = lbx[0][t.b].lo[q]; nd.bmax[q] = lbx[0][t.b].hi[q]; }
+            nd.left = -1; nd.right = -1; nd.prim = lid[0][t.b];
+            out[t.slot] = nd;
+            continue;
+        }
+        if (t.depth > guard_depth) { atomicAdd(&ctl->too_deep, 1u); return; }
+        int best_axis = 0, best_k = m / 2, best_off = 0;
+        double best_cost = 0.0;
+        SB whole = empty_host();
+        for (int a = 0; a < 3; a++) {
+            SB acc = empty_host();
+            for (int j = t.e - 1; j > t.b; j--) {                 // suf[j] = area of the box of [j, e)
+                merge_host(acc, lbx[a][j]);
+                suf[j] = area_like_host(acc);
+            }
+            SB w = acc;
+            merge_host(w, lbx[a][t.b]);
+            if (a == 0) whole = w;
+            acc = empty_host();
+            bool have = false;
+            double a_cost = 0.0;
+            int a_off = 0, a_k = 0;
+            for (int k = 1; k < m; k++) {                          // cut after the first k of this order
+                merge_host(acc, lbx[a][t.b + k - 1]);
+                const double cost = area_like_host(acc) * k + suf[t.b + k] * (m - k);
+                const int off = 2 * k > m ? 2 * k - m : m - 2 * k;
+                if (!have || cost < a_cost || (cost == a_cost && off < a_off)) { have = true; a_cost = cost; a_off = off; a_k = k; }
+            }
+            if (a == 0 || a_cost < best_cost || (a_cost == best_cost && a_off < best_off)) {
+                best_axis = a; best_cost = a_cost; best_off = a_off; best_k = a_k;
+            }
+        }
+        // the other two orders follow: stable partition by membership in the left set
+        for (int j = t.b; j < t.b + best_k; j++) left[lid[best_axis][j]] = 1;
+        for (int o = 1; o <= 2; o++) {
+            const int a = (best_axis + o) % 3;
+            int l = t.b, r = 0;
+            for (int j = t.b; j < t.e; j++) {
+                const int32_t p = lid[a][j];
+                if (left[p]) { lid[a][l] = p; lbx[a][l] = lbx[a][j]; l++; } else { tid[r] = p; tbx[r] = lbx[a][j]; r++; }
+            }
+            for (int j = 0; j < r; j++) { lid[a][l + j] = tid[j]; lbx[a][l + j] = tbx[j]; }
+        }
+        for (int j = t.b; j < t.b + best_k; j++) left[lid[best_axis][j]] = 0;
+        for (int q = 0; q < 3; q++) { nd.bmin[q] = whole.lo[q]; nd.bmax[q] = whole.hi[q]; }
+        nd.prim = -1;
+        nd.left = t.slot + 1;
+        nd.right = t.slot + 2 * best_k;
+        out[t.slot] = nd;
+        todo[top++] = Task{(int16_t)(t.b + best_k), t.e, nd.right, (int16_t)(t.depth + 1)};
+        todo[top++] = Task{t.b, (int16_t)(t.b + best_k), nd.left, (int16_t)(t.depth + 1)};
+    }
+    atomicMax(&ctl->max_depth, deepest);
 }
 
 // the first k positions of the chosen axis' order are the left set
@@ -361,7 +468,8 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
         auto vr = rocprim::make_reverse_iterator(sb + n);
         HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box_r, kr, vr, vr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
         HIPS(rocprim::exclusive_scan_by_key(nullptr, t_scan_u, k32, u3, u3, U3{{0u, 0u, 0u}}, (size_t)n, Plus3(), rocprim::equal_to<uint32_t>(), nullptr));
-        HIPS(rocprim::reduce_by_key(nullptr, t_reduce, k32, cd, (size_t)n, k32, cd, cnt, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
+        HIPS(rocprim::inclusive_scan_by_key(nullptr, t_reduce, k32, cd, cd, (size_t)n, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
+        (void)cnt;
     }
     const size_t t_bytes = std::max(std::max(std::max(t_sort, t_scan_box), std::max(t_scan_box_r, t_scan_u)), t_reduce);
     const size_t nn = (size_t)n;
@@ -425,10 +533,9 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
         }
         hipLaunchKernelGGL(cand3_kernel, dim3(G), dim3(T), 0, nullptr, pre, suf, cur_b, cur_e, n, best.p, whole.p);
         tb = t_bytes;
-        HIPS(rocprim::reduce_by_key(temp.p, tb, cur_b, best.p, (size_t)n, uniq.p, best_seg.p, n_seg.p, CandMin(),
-                                    rocprim::equal_to<uint32_t>(), nullptr));
-        HIPS(hipMemsetAsync(ctl.p, 0, sizeof(unsigned int) * 2, nullptr));           // active, too_deep (max_depth stays)
-        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, uniq.p, best_seg.p, n_seg.p, cur_e, whole.p, cur_idx, cur_bx.a[0],
+        HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, best.p, best_seg.p, (size_t)n, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
+        HIPS(hipMemsetAsync(ctl.p, 0, sizeof(unsigned int) * 3, nullptr));           // active, too_deep, max_child (max_depth stays)
+        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, best_seg.p, cur_b, cur_e, whole.p, cur_idx, cur_bx.a[0], n,
                            slot.p, split.p, nodes.p, depth, guard_depth, ctl.p);
         HIPS(hipGetLastError());
         HIPS(hipMemcpy(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost));
@@ -446,6 +553,15 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
         std::swap(cur_idx, alt_idx);
         std::swap(cur_b, alt_b);
         std::swap(cur_e, alt_e);
+        if (h.max_child <= (unsigned int)kSmall) {
+            // every node of the next level is small: one thread each finishes its subtree (finish_small_kernel)
+            hipLaunchKernelGGL(finish_small_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, cur_idx, cur_bx, cur_b, cur_e, n, slot.p, left.p,
+                               nodes.p, depth + 1, guard_depth, ctl.p);
+            HIPS(hipGetLastError());
+            HIPS(hipMemcpy(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost));
+            if (h.too_deep) return pt_fail(PT_ERR_UNSUPPORTED, "sweep_build_device: a branch beyond the depth guard (host builder takes over)");
+            break;
+        }
     }
     HIPS(hipEventRecord(ev1, nullptr));
     HIPS(hipEventSynchronize(ev1));
