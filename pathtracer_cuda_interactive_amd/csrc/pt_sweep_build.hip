@@ -14,8 +14,8 @@
 //   * per axis: the boxes of all prefixes and of all suffixes of every range = two segmented scans (min / max do not round, the
 //     scan's operator keeps the EARLIER operand on ties exactly as the host's sequential merge does, so the very bits — the
 //     sign of a zero included — are the host's); cost of the cut after position i in fp64 with the host's operand order;
-//   * best cut of every node = a reduction by key over (cost, |2k - m|, axis, k), a total order: any reduction tree gives the
-//     host's choice;
+//   * best cut of every node = a segmented min-scan over (cost, |2k - m|, axis, k), a total order: any association gives the
+//     host's choice (read at the node's last position);
 //   * the two other orders follow by a stable partition per node = an exclusive segmented scan of the "goes left" flags;
 //   * a node's slot in the pre-order output follows from its parent's: left = slot + 1, right = slot + 2 k.
 // One level costs ~35 small launches whatever n is; the levels of a million-primitive tree take a few milliseconds together.
@@ -24,7 +24,6 @@
 #include <hip/hip_runtime.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_reduce_by_key.hpp>
 #include <rocprim/device/device_scan_by_key.hpp>
 #include <rocprim/iterator/reverse_iterator.hpp>
 
@@ -103,41 +102,9 @@ __global__ void sort_keys_kernel(const SB* __restrict__ boxes, int n, int axis, 
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                      // unsigned order = float order
     keys[i] = ((unsigned long long)u << 32) | (unsigned long long)(uint32_t)i;      // (centroid, id): a total order
 }
-__global__ void gather_order_kernel(const unsigned long long* __restrict__ keys, const SB* __restrict__ boxes, int n,
-                                    int32_t* __restrict__ idx, SB* __restrict__ bx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t p = (int32_t)(uint32_t)keys[i];
-    idx[i] = p;
-    bx[i] = boxes[p];
-}
-
 // ---- one level ---------------------------------------------------------------------------------------------------------------
-struct Level {                  // per position (same for all three orders)
-    uint32_t* seg_b;            // start of the node's range = the scan key
-    uint32_t* seg_e;            // its end
-};
-
-// Cuts along `axis`: the candidate of position i = the cut after i (k = i - b + 1 primitives go left), folded into best[i].
-// axis 0 also records the box of the whole node at its first position.
-__global__ void cand_kernel(const SB* __restrict__ pre, const SB* __restrict__ suf, const uint32_t* __restrict__ seg_b,
-                            const uint32_t* __restrict__ seg_e, int n, int axis, Cand* __restrict__ best, SB* __restrict__ whole) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t b = seg_b[i], e = seg_e[i];
-    if (axis == 0 && (uint32_t)i == b) whole[b] = clamp_like_host(suf[i]);
-    Cand c = cand_none();
-    if ((uint32_t)i + 1 < e) {
-        const int k = i - (int)b + 1, m = (int)(e - b);
-        c.cost = area_like_host(clamp_like_host(pre[i])) * k + area_like_host(clamp_like_host(suf[i + 1])) * (m - k);
-        c.off = 2 * k > m ? 2 * k - m : m - 2 * k;
-        c.ak = (axis << 28) | k;
-    }
-    best[i] = axis == 0 ? c : CandMin()(best[i], c);
-}
-
-// The three orders side by side: element i = position i of the x-, y- and z-order.  All three share their node ranges, so one
-// segmented scan over triples does the work of three (a third of the launches; the levels of a build are launch-bound).
+// The three orders side by side: position i of the x-, y- and z-order.  All three share their node ranges, so the cut search,
+// the flags, their ranks and the partition each take one pass for all three (the box scans stay per order).
 struct SB3 { SB* a[3]; };        // the boxes of the three orders: one array per order (24-B elements scan faster than 72-B ones)
 struct I3 { int32_t a[3]; };
 struct U3 { uint32_t a[3]; };
@@ -363,41 +330,6 @@ __global__ __launch_bounds__(64) void finish_small_kernel(const I3* __restrict__
     atomicMax(&ctl->max_depth, deepest);
 }
 
-// the first k positions of the chosen axis' order are the left set
-__global__ void mark_left_kernel(const uint32_t* __restrict__ seg_b, const int32_t* __restrict__ split, const int32_t* __restrict__ idx0,
-                                 const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2, int n, unsigned char* __restrict__ left) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t b = seg_b[i];
-    const int32_t sp = split[b];
-    const int axis = sp >> 28, k = sp & 0x0fffffff;
-    if (i - (int)b < k) {
-        const int32_t* ix = axis == 0 ? idx0 : axis == 1 ? idx1 : idx2;
-        left[ix[i]] = 1;
-    }
-}
-__global__ void flags_kernel(const int32_t* __restrict__ idx, const unsigned char* __restrict__ left, int n, uint32_t* __restrict__ f) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) f[i] = left[idx[i]];
-}
-// stable partition of every range by the flags (rank = exclusive segmented sum of the flags); order 0 also moves the ranges
-__global__ void scatter_kernel(const int32_t* __restrict__ idx, const SB* __restrict__ bx, const uint32_t* __restrict__ f,
-                               const uint32_t* __restrict__ rank, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
-                               const int32_t* __restrict__ split, int n, int32_t* __restrict__ idx_out, SB* __restrict__ bx_out,
-                               uint32_t* __restrict__ seg_b_out, uint32_t* __restrict__ seg_e_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t b = seg_b[i], e = seg_e[i];
-    const uint32_t k = (uint32_t)(split[b] & 0x0fffffff);
-    const uint32_t r = rank[i];
-    const uint32_t dest = f[i] ? b + r : b + k + ((uint32_t)i - b - r);
-    idx_out[dest] = idx[i];
-    bx_out[dest] = bx[i];
-    if (seg_b_out) {
-        seg_b_out[dest] = f[i] ? b : b + k;
-        seg_e_out[dest] = f[i] ? b + k : e;
-    }
-}
 __global__ void init_segments_kernel(int n, uint32_t* __restrict__ seg_b, uint32_t* __restrict__ seg_e, int32_t* __restrict__ slot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -452,16 +384,15 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     struct { I3* p; } idx, idx_alt;
     struct { int32_t* p; } slot, split;
     struct { unsigned long long* p; } keys, keys_alt;
-    struct { uint32_t* p; } seg_b, seg_e, seg_b_alt, seg_e_alt, uniq;
+    struct { uint32_t* p; } seg_b, seg_e, seg_b_alt, seg_e_alt;
     struct { U3* p; } flags, rank;
     struct { Cand* p; } best, best_seg;
     struct { unsigned char* p; } left, temp;
     struct { BuildCtl* p; } ctl;
-    struct { unsigned int* p; } n_seg;
     // temporary storage of the rocPRIM calls: the largest of the five kinds, sized once (size queries read no memory)
     size_t t_sort = 0, t_scan_box = 0, t_scan_box_r = 0, t_scan_u = 0, t_reduce = 0;
     {
-        unsigned long long* k64 = nullptr; uint32_t* k32 = nullptr; SB* sb = nullptr; Cand* cd = nullptr; unsigned int* cnt = nullptr; U3* u3 = nullptr;
+        unsigned long long* k64 = nullptr; uint32_t* k32 = nullptr; SB* sb = nullptr; Cand* cd = nullptr; U3* u3 = nullptr;
         HIPS(rocprim::radix_sort_keys(nullptr, t_sort, k64, k64, (size_t)n, 0, 64, nullptr));
         HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box, k32, sb, sb, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
         auto kr = rocprim::make_reverse_iterator(k32 + n);
@@ -469,7 +400,6 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
         HIPS(rocprim::inclusive_scan_by_key(nullptr, t_scan_box_r, kr, vr, vr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
         HIPS(rocprim::exclusive_scan_by_key(nullptr, t_scan_u, k32, u3, u3, U3{{0u, 0u, 0u}}, (size_t)n, Plus3(), rocprim::equal_to<uint32_t>(), nullptr));
         HIPS(rocprim::inclusive_scan_by_key(nullptr, t_reduce, k32, cd, cd, (size_t)n, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
-        (void)cnt;
     }
     const size_t t_bytes = std::max(std::max(std::max(t_sort, t_scan_box), std::max(t_scan_box_r, t_scan_u)), t_reduce);
     const size_t nn = (size_t)n;
@@ -478,9 +408,9 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     const size_t o_idx = arena.reserve(nn * sizeof(I3)), o_idxa = arena.reserve(nn * sizeof(I3)), o_whole = arena.reserve(nn * sizeof(SB));
     const size_t o_slot = arena.reserve(nn * 4), o_split = arena.reserve(nn * 4), o_keys = arena.reserve(nn * 8), o_keysa = arena.reserve(nn * 8);
     const size_t o_sb = arena.reserve(nn * 4), o_se = arena.reserve(nn * 4), o_sba = arena.reserve(nn * 4), o_sea = arena.reserve(nn * 4);
-    const size_t o_flags = arena.reserve(nn * sizeof(U3)), o_rank = arena.reserve(nn * sizeof(U3)), o_uniq = arena.reserve(nn * 4);
+    const size_t o_flags = arena.reserve(nn * sizeof(U3)), o_rank = arena.reserve(nn * sizeof(U3));
     const size_t o_best = arena.reserve(nn * sizeof(Cand)), o_bests = arena.reserve(nn * sizeof(Cand)), o_left = arena.reserve(nn);
-    const size_t o_ctl = arena.reserve(sizeof(BuildCtl)), o_nseg = arena.reserve(sizeof(unsigned int)), o_temp = arena.reserve(t_bytes);
+    const size_t o_ctl = arena.reserve(sizeof(BuildCtl)), o_temp = arena.reserve(t_bytes);
     HIPS(hipMalloc(reinterpret_cast<void**>(&arena.base), arena.used));
     for (int a = 0; a < 3; a++) {
         bx.a[a] = reinterpret_cast<SB*>(arena.base + o_bx[a]); bx_alt.a[a] = reinterpret_cast<SB*>(arena.base + o_bxa[a]);
@@ -492,10 +422,10 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     keys.p = reinterpret_cast<unsigned long long*>(arena.base + o_keys); keys_alt.p = reinterpret_cast<unsigned long long*>(arena.base + o_keysa);
     seg_b.p = reinterpret_cast<uint32_t*>(arena.base + o_sb); seg_e.p = reinterpret_cast<uint32_t*>(arena.base + o_se);
     seg_b_alt.p = reinterpret_cast<uint32_t*>(arena.base + o_sba); seg_e_alt.p = reinterpret_cast<uint32_t*>(arena.base + o_sea);
-    flags.p = reinterpret_cast<U3*>(arena.base + o_flags); rank.p = reinterpret_cast<U3*>(arena.base + o_rank); uniq.p = reinterpret_cast<uint32_t*>(arena.base + o_uniq);
+    flags.p = reinterpret_cast<U3*>(arena.base + o_flags); rank.p = reinterpret_cast<U3*>(arena.base + o_rank);
     best.p = reinterpret_cast<Cand*>(arena.base + o_best); best_seg.p = reinterpret_cast<Cand*>(arena.base + o_bests);
     left.p = arena.base + o_left; temp.p = arena.base + o_temp;
-    ctl.p = reinterpret_cast<BuildCtl*>(arena.base + o_ctl); n_seg.p = reinterpret_cast<unsigned int*>(arena.base + o_nseg);
+    ctl.p = reinterpret_cast<BuildCtl*>(arena.base + o_ctl);
 
     hipEvent_t ev0, ev1;
     HIPS(hipEventCreate(&ev0));
