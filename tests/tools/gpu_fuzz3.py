@@ -1,0 +1,80 @@
+"""Fuzz of round 3's new paths.  (a) Scenes of 4,096+ shapes — prepared on the device (pt_scene_prep.hip, pt_sweep_build.hip): the
+frame must equal the oracle's on the CALLER's tree bit for bit, the work counters the oracle's, and the device-built internal
+tree the host builder's byte for byte.  (b) LDS-resident scenes on the regrouped kernel (option kernel = 3) with random schedule
+knobs: frame and counters bit-identical to the oracle.  Usage: python tests/tools/gpu_fuzz3.py [n_scenes]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import oracle_binding as ob  # noqa: E402
+from conftest import random_scene  # noqa: E402
+from test_fast_tree import scene_with_ties  # noqa: E402
+from pathtracer_cuda_interactive_amd import device as dev  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(3003)
+t0 = time.time()
+big = small = on_dev = q_runs = reruns = 0
+for k in range(n):
+    if k % 2 == 0:
+        n_tris = int(rng.choice([4100, 5000, 6000, 9000, 14000, 25000]))
+        if k % 6 == 4:
+            hs = scene_with_ties(3000 + k, n_tris=n_tris)
+        else:
+            hs = random_scene(3000 + k, n_tris=n_tris, n_spheres=int(rng.integers(0, 6)), emissive=bool(rng.integers(0, 2)))
+        d = hs.finalize(int(rng.integers(0, 2)))
+        w, h, spp = [(48, 36, 2), (33, 17, 3), (64, 8, 2)][k % 3]
+        p = hs.render_params(w, h, spp, seed=int(rng.integers(0, 1 << 30)))
+        want, cnt = ob.render(d, p)
+        ds = dev.DeviceScene(d)
+        ds.set_option("stats", 1)
+        img = ds.render(p)
+        c = ds.counters()
+        ok = bool((img.view(np.uint32) == want.view(np.uint32)).all()) and (c.paths, c.segments) == (cnt.paths, cnt.segments)
+        on_dev += ds.info("sweep_on_device")
+        reruns += ds.info("redo_segments")
+        ds.set_option("fast_tree", 0)
+        img0 = ds.render(p)
+        c0 = ds.counters()
+        ok = ok and bool((img0.view(np.uint32) == want.view(np.uint32)).all())
+        ok = ok and (c0.node_visits, c0.leaf_tests) == (cnt.inner_pops, cnt.leaf_tri + cnt.leaf_sphere)
+        ds.close()
+        _, th = dev.build_bvh_sweep(d)
+        try:
+            _, td = dev.build_bvh_sweep(d, on_device=True)
+            ok = ok and th["nodes"].tobytes() == td["nodes"].tobytes() and th["depth"] == td["depth"]
+        except Exception as e:          # noqa: BLE001  (input beyond the depth guard is handed back: allowed, must say so)
+            ok = ok and "UNSUPPORTED" in str(e)
+        big += 1
+    else:
+        n_tris = int(rng.choice([0, 2, 7, 30, 60, 150, 230]))
+        hs = random_scene(3000 + k, n_tris=n_tris, n_spheres=int(rng.integers(0, 6)) if n_tris else int(rng.integers(1, 6)),
+                          emissive=bool(rng.integers(0, 2)))
+        d = hs.finalize(int(rng.integers(0, 2)))
+        w, h, spp = [(48, 36, 3), (33, 17, 5), (64, 8, 2), (20, 50, 4)][k % 4]
+        p = hs.render_params(w, h, spp, seed=int(rng.integers(0, 1 << 30)))
+        p.max_depth = int(rng.choice([50, 50, 3, 1]))
+        want, cnt = ob.render(d, p)
+        ds = dev.DeviceScene(d)
+        ds.set_option("kernel", 3)
+        ds.set_option("q_target", int(rng.choice([0, 64, 300, 700, 100000])))
+        ds.set_option("q_swap", int(rng.choice([0, 1, 8, 32, 64])))
+        ds.set_option("q_low", int(rng.choice([0, 1, 64, 1000])))
+        img = ds.render(p)
+        c = ds.counters()
+        ok = bool((img.view(np.uint32) == want.view(np.uint32)).all()) and (c.paths, c.segments) == (cnt.paths, cnt.segments)
+        q_runs += 1 if ds.info("kernel") == 3 else 0
+        ds.close()
+        small += 1
+    if not ok:
+        print(f"MISMATCH scene {k}: tris {n_tris}")
+        sys.exit(1)
+    if k % 50 == 49:
+        print(f"{k + 1} scenes ok, {time.time() - t0:.1f} s", flush=True)
+print(f"fuzz3 ok: {big} scenes of 4,096+ shapes ({on_dev} prepared on the device, device-built internal trees byte-identical to the host builder's, "
+      f"{reruns} segments traced on the caller's tree), {small} small scenes of which {q_runs} ran on the regrouped kernel with random schedule knobs")
