@@ -232,7 +232,7 @@ int pt_bvh_build_sweep_device(const pt_scene_desc* desc, pt_bvh_node* out_nodes,
 
 /* Tuning knobs (all optional; none of them changes a bit of the rendered image):
  *   "kernel"        2 (default) decoupled traversal/shading scheduler, 1 segment-synchronous wavefront kernel, 3 paths regrouped
- *                   across the waves of a workgroup through LDS rings (csrc/pt_kernel_q.h; LDS-resident scenes with exact traversal,
+ *                   across the waves of a workgroup through LDS rings (csrc/pt_kernel_q.h; exact traversal without PT_RENDER_NEE,
  *                   anything else runs on 2; "q_target" / "q_swap" / "q_low" are its schedule knobs, 0 = automatic)
  *   "v2_thresh" / "v2_inner" / "v2_minw"   scheduler variant of kernel 2; 0 = automatic (by scene residency).
  *                   v2_inner: < 0 vote burst of -n steps; 1..9 n inner steps + 1 leaf step per burst; >= 100 encodes

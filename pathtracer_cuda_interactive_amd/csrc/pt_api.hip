@@ -838,32 +838,52 @@ TraceFn pick_kernel_nee(int res, bool stats, int spec) {
 
 // trace_kernel_q (option "kernel" = 3): LDS-resident scenes, exact traversal, no next-event estimation.
 using TraceFnQ = void (*)(SceneDev, RenderDev, LdsPlan, QParams, float4*, uint32_t*, unsigned long long*);
-template <int RES>
+template <int RES, bool POSTPONE>
 TraceFnQ pick_q_r(bool stats, int spec) {
-    if (spec == 2) return stats ? trace_kernel_q<RES, true, 2> : trace_kernel_q<RES, false, 2>;
-    if (spec == 1) return stats ? trace_kernel_q<RES, true, 1> : trace_kernel_q<RES, false, 1>;
-    return stats ? trace_kernel_q<RES, true, 0> : trace_kernel_q<RES, false, 0>;
+    if (spec == 2) return stats ? trace_kernel_q<RES, true, 2, POSTPONE> : trace_kernel_q<RES, false, 2, POSTPONE>;
+    if (spec == 1) return stats ? trace_kernel_q<RES, true, 1, POSTPONE> : trace_kernel_q<RES, false, 1, POSTPONE>;
+    return stats ? trace_kernel_q<RES, true, 0, POSTPONE> : trace_kernel_q<RES, false, 0, POSTPONE>;
 }
-TraceFnQ pick_kernel_q(const pt_scene* S, int res) {
+// internal_tree: scenes in global memory set leaves aside (order-free leaf tests need the internal tree's tie handling)
+TraceFnQ pick_kernel_q(const pt_scene* S, int res, bool internal_tree) {
     const int spec = !(S->tri_only && S->opt_specialize) ? 0 : (S->diffuse_only ? 2 : 1);
-    return res == 2 ? pick_q_r<2>(S->opt_stats != 0, spec) : pick_q_r<1>(S->opt_stats != 0, spec);
+    const bool stats = S->opt_stats != 0;
+    if (res == 2) return pick_q_r<2, false>(stats, spec);
+    if (res == 1) return pick_q_r<1, false>(stats, spec);
+    if (res == 3) return internal_tree ? pick_q_r<3, true>(stats, spec) : pick_q_r<3, false>(stats, spec);
+    return internal_tree ? pick_q_r<0, true>(stats, spec) : pick_q_r<0, false>(stats, spec);
 }
 
 // LDS plan of trace_kernel_q: the staged scene as for v2, 16-bit traversal stacks for the kQT traversal waves only, then the
 // control words and the two rings (contiguous: the kernel clears them in one sweep).  Also settles the schedule knobs.
-QParams make_plan_q(const pt_scene* S, LdsPlan& lp, int which) {
+QParams make_plan_q(const pt_scene* S, LdsPlan& lp, int which, int res) {
     QParams q{};
-    uint32_t off = lp.stack_off + (uint32_t)kQT * (uint32_t)S->tree[which].stack_cap * 64u * 2u;
-    off = align16(off);
+    const bool lds_scene = res == 1 || res == 2;
+    const uint32_t stack_bytes = (uint32_t)kQT * (uint32_t)S->tree[which].stack_cap * 64u * (lds_scene ? 2u : 4u);
+    // scenes in global memory carry 32-bit stacks as deep as the tree's Strahler number: they run with rings of half the size, and
+    // the top of the tree takes what two workgroups per CU leave (160 KB / 2, minus stacks and rings)
+    uint32_t ring = kQRing;
+    if (!lds_scene) ring = std::max<uint32_t>(64u, kQRing / 2);
+    q.ring_log2 = 0;
+    while ((1u << q.ring_log2) < ring) q.ring_log2++;
+    const uint32_t ring_bytes = kQCtlBytes + 2u * ring * kQEntryBytes;
+    if (res == 3) {
+        const uint32_t budget = S->opt_lds_budget_kb > 0 ? (uint32_t)S->opt_lds_budget_kb * 1024u : 80u * 1024u;
+        const uint32_t used = stack_bytes + ring_bytes + 64u;
+        lp.top_count = std::min<uint32_t>(S->tree[which].top_avail, budget > used ? (budget - used) / (uint32_t)sizeof(DNode) : 0u);
+        lp.nodes_off = 0;
+        lp.stack_off = lp.top_count * (uint32_t)sizeof(DNode);
+    }
+    uint32_t off = align16(lp.stack_off + stack_bytes);
     q.ctl_off = off; off += kQCtlBytes;
-    q.shade_off = off; off += kQRing * kQEntryBytes;
-    q.ready_off = off; off += kQRing * kQEntryBytes;
+    q.shade_off = off; off += ring * kQEntryBytes;
+    q.ready_off = off; off += ring * kQEntryBytes;
     lp.total = align16(off);
     // Paths in flight per workgroup.  The bound that keeps the rings from filling up for good (pt_kernel_q.h): with every
     // T-lane holding a finished path, a ring that cannot take a wave's worth more (> ring - 64 entries each) — that many
     // paths must not exist:  target <= T-lanes + 2 x ring - 128.
-    const int32_t t_lanes = kQT * 64, cap = t_lanes + 2 * (int32_t)kQRing - 128;
-    int32_t target = S->opt_q_target > 0 ? (int32_t)S->opt_q_target : t_lanes + (int32_t)kQRing;
+    const int32_t t_lanes = kQT * 64, cap = t_lanes + 2 * (int32_t)ring - 128;
+    int32_t target = S->opt_q_target > 0 ? (int32_t)S->opt_q_target : t_lanes + (int32_t)ring;
     q.target = std::max(64, std::min(target, cap));
     q.swap = S->opt_q_swap > 0 ? (int32_t)std::min<int64_t>(S->opt_q_swap, 64) : 16;
     q.low = S->opt_q_low > 0 ? (int32_t)S->opt_q_low : 8;
@@ -1017,16 +1037,16 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     const bool nee = (p->flags & PT_RENDER_NEE) != 0;
     if (nee && (S->opt_kernel < 2 || traversal != PT_TRAVERSAL_EXACT))
         return fail(PT_ERR_UNSUPPORTED, "PT_RENDER_NEE runs on the default kernel with exact traversal only");
-    // kernel 3 (paths regrouped across the waves of a workgroup) serves LDS-resident scenes with exact traversal; everything
-    // else runs on kernel 2
-    const bool use_q = S->opt_kernel == 3 && lds_scene && !nee && traversal == PT_TRAVERSAL_EXACT;
+    // kernel 3 (paths regrouped across the waves of a workgroup) serves exact traversal without next-event estimation; those run
+    // on kernel 2
+    const bool use_q = S->opt_kernel == 3 && !nee && traversal == PT_TRAVERSAL_EXACT;
     QParams qp{};
     TraceFnQ fnq = nullptr;
     TraceFn fn = nullptr;
     if (use_q) {
-        qp = make_plan_q(S, lp, which);
+        qp = make_plan_q(S, lp, which, res);
         if (lp.total > S->lds_per_block_max) return fail(PT_ERR_DEVICE, "LDS plan exceeds the per-block limit");
-        fnq = pick_kernel_q(S, res);
+        fnq = pick_kernel_q(S, res, which == 1);
     } else {
         fn = nee ? pick_kernel_nee(res, S->opt_stats != 0, (S->tri_only && S->diffuse_only && S->opt_specialize) ? 2 : 0)
                  : pick_kernel(S, res, traversal == PT_TRAVERSAL_PRUNED, S->opt_stats != 0, which == 1);
@@ -1384,8 +1404,8 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
         const int w = which_tree(S);
         const int res = scene_residency(S, w);
         const void* f;
-        if (S->opt_kernel == 3 && (res == 1 || res == 2) && k == "vgprs") {
-            f = reinterpret_cast<const void*>(pick_kernel_q(S, res));
+        if (S->opt_kernel == 3 && k == "vgprs") {
+            f = reinterpret_cast<const void*>(pick_kernel_q(S, res, w == 1));
         } else {
             TraceFn fn = pick_kernel(S, res, k == "vgprs_pruned", S->opt_stats != 0, w == 1);
             if (!fn) return fail(PT_ERR_INVALID_ARG, "no such kernel variant");

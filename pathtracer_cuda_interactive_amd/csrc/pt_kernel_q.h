@@ -1,5 +1,5 @@
 // pt_kernel_q.h — trace_kernel_q: the path tracer with paths REGROUPED ACROSS THE WAVES OF A WORKGROUP by what they need next
-// (included only by pt_api.hip; option "kernel" = 3, LDS-resident scenes).
+// (included only by pt_api.hip; option "kernel" = 3; every residency, exact traversal, no next-event estimation).
 //
 // trace_kernel_v2 keeps one path per lane for the path's whole life: a lane whose traversal is finished waits until enough
 // lanes of ITS wave wait with it before the wave shades and refills (47 % of its VALU lane slots do work on cbox).  Here the
@@ -53,7 +53,8 @@ namespace ptk {
 constexpr int kQT = PT_Q_NT;                        // traversal waves per workgroup
 constexpr int kQS = PT_Q_NS;                        // shading waves per workgroup
 constexpr int kQBlock = (kQT + kQS) * 64;
-constexpr uint32_t kQRing = PT_Q_RING;              // entries per ring (power of two)
+constexpr uint32_t kQRing = PT_Q_RING;              // entries per ring (power of two) for LDS-resident scenes; scenes in global memory,
+                                                    // whose traversal stacks are 32-bit and deeper, run with half of it (QParams::ring_log2)
 constexpr uint32_t kQEntryBytes = 96;               // 24 words: 22 of path, flag, pad
 constexpr uint32_t kQCtlBytes = 64;
 constexpr uint32_t kQSpinLimit = 1u << 22;
@@ -66,6 +67,7 @@ struct QParams {
     int32_t swap;        // a T-wave exchanges finished / empty lanes with the rings when at least this many lanes want it
     int32_t low;         // an S-wave shades a partial batch (fewer than 64 finished paths) only while the ready ring holds fewer rays than this
     uint32_t ctl_off, shade_off, ready_off;   // LDS byte offsets: control words, the two rings
+    uint32_t ring_log2;  // entries per ring = 1 << ring_log2
 };
 
 using ptd::f4v;
@@ -82,13 +84,13 @@ enum { kQsHead = 0, kQsTail = 1, kQrHead = 2, kQrTail = 3, kQLive = 4, kQFeedsOp
 __device__ __forceinline__ uint32_t q_load(lds_u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, PT_Q_WG); }
 
 // Wave-uniform.  Reserves n consecutive ring positions for writing; false when the ring has no room for them right now.
-__device__ __forceinline__ bool q_reserve(lds_u32* head_tail, uint32_t n, int lane, uint32_t& pos) {
+__device__ __forceinline__ bool q_reserve(lds_u32* head_tail, uint32_t n, int lane, uint32_t& pos, uint32_t ring) {
     uint32_t ok = 0, p = 0;
     if (lane == 0) {
         for (int tries = 0; tries < 8 && !ok; tries++) {
             const uint32_t head = q_load(head_tail);
             uint32_t tail = q_load(head_tail + 1);
-            if (tail + n - head > kQRing) break;             // a stale head only makes this stricter
+            if (tail + n - head > ring) break;               // a stale head only makes this stricter
             if (__hip_atomic_compare_exchange_strong(head_tail + 1, &tail, tail + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, PT_Q_WG)) {
                 ok = 1; p = tail;
             }
@@ -130,17 +132,17 @@ struct QPath {
 
 constexpr uint32_t kQRedoBit = 0x80000000u;
 
-__device__ __forceinline__ unsigned char* q_entry(unsigned char* ring, uint32_t pos) {
+__device__ __forceinline__ unsigned char* q_entry(unsigned char* ring, uint32_t pos, uint32_t rl) {
     // An entry is kept as two halves of 48 B in two arrays (words 0..11 in the first, 12..23 — the sequence word among them —
-    // kQRing x 48 B further on): consecutive lanes move consecutive entries, and 128-bit LDS accesses 48 B apart touch every
+    // ring x 48 B further on): consecutive lanes move consecutive entries, and 128-bit LDS accesses 48 B apart touch every
     // bank once, where a 96-B pitch put two lanes of each group on the same banks (40 % of the LDS cycles were conflicts).
-    return ring + (pos & (kQRing - 1)) * (kQEntryBytes / 2);
+    return ring + (pos & ((1u << rl) - 1u)) * (kQEntryBytes / 2);
 }
-constexpr uint32_t kQHalf = kQRing * (kQEntryBytes / 2);      // byte distance between the two halves of an entry
+__device__ __forceinline__ uint32_t q_half(uint32_t rl) { return (kQEntryBytes / 2) << rl; }      // byte distance between the two halves of an entry
 // Sequence word of position `pos` when it is free for its producer (see the header of this file).
-__device__ __forceinline__ uint32_t q_seq(uint32_t pos) { return (pos / kQRing) * 2u; }
+__device__ __forceinline__ uint32_t q_seq(uint32_t pos, uint32_t rl) { return (pos >> rl) * 2u; }
 // ... and the sequence arithmetic wraps where the 32-bit positions do (after 2^32 / ring laps)
-constexpr uint32_t kQSeqMask = (uint32_t)((((1ull << 32) / kQRing) * 2ull) - 1ull);
+__device__ __forceinline__ uint32_t q_seq_mask(uint32_t rl) { return (uint32_t)((2ull << (32u - rl)) - 1ull); }
 
 // error bits: 1 a bounded wait ran out, 2 an entry failed its check word, 4 a path carried an impossible primitive or sample index
 __device__ __forceinline__ void q_flag_error(lds_u32* ctl, uint32_t bits = 1u) { __hip_atomic_fetch_or(ctl + kQError, bits, __ATOMIC_RELAXED, PT_Q_WG); }
@@ -159,10 +161,10 @@ __device__ __forceinline__ uint32_t q_check_word(const QPath& p) {
 }
 
 // Producer side of one entry (the position has been reserved): wait until its last reader is done, write, publish.
-__device__ __forceinline__ void q_write(unsigned char* ring, uint32_t pos, const QPath& p, lds_u32* ctl) {
-    unsigned char* e = q_entry(ring, pos);
-    unsigned char* e2 = e + kQHalf;
-    const uint32_t seq = q_seq(pos);
+__device__ __forceinline__ void q_write(unsigned char* ring, uint32_t pos, const QPath& p, lds_u32* ctl, uint32_t rl) {
+    unsigned char* e = q_entry(ring, pos, rl);
+    unsigned char* e2 = e + q_half(rl);
+    const uint32_t seq = q_seq(pos, rl);
     lds_u32* flag = (lds_u32*)(e2 + 40);
     uint32_t spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, PT_Q_WG) != seq) {
@@ -185,10 +187,10 @@ __device__ __forceinline__ void q_write(unsigned char* ring, uint32_t pos, const
 }
 
 // Consumer side (the position has been claimed): wait until the producer has published it, read, hand the entry back.
-__device__ __forceinline__ void q_read(unsigned char* ring, uint32_t pos, QPath& p, lds_u32* ctl) {
-    unsigned char* e = q_entry(ring, pos);
-    unsigned char* e2 = e + kQHalf;
-    const uint32_t seq = q_seq(pos);
+__device__ __forceinline__ void q_read(unsigned char* ring, uint32_t pos, QPath& p, lds_u32* ctl, uint32_t rl) {
+    unsigned char* e = q_entry(ring, pos, rl);
+    unsigned char* e2 = e + q_half(rl);
+    const uint32_t seq = q_seq(pos, rl);
     lds_u32* flag = (lds_u32*)(e2 + 40);
     uint32_t spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, PT_Q_WG) != seq + 1u) {
@@ -208,7 +210,7 @@ __device__ __forceinline__ void q_read(unsigned char* ring, uint32_t pos, QPath&
     p.rng.inc = (uint64_t)__builtin_bit_cast(uint32_t, s2) | ((uint64_t)__builtin_bit_cast(uint32_t, s3) << 32);
     p.depth_flags = __builtin_bit_cast(uint32_t, d0); p.my_w = __builtin_bit_cast(uint32_t, d1);
     const uint32_t chk = PT_Q_CHECK ? *(lds_u32*)(e2 + 44) : 0u;
-    __hip_atomic_store(flag, (seq + 2u) & kQSeqMask, __ATOMIC_RELEASE, PT_Q_WG);
+    __hip_atomic_store(flag, (seq + 2u) & q_seq_mask(rl), __ATOMIC_RELEASE, PT_Q_WG);
     if (PT_Q_CHECK && chk != q_check_word(p)) q_flag_error(ctl, 2u);
 }
 
@@ -216,7 +218,10 @@ __device__ __forceinline__ void q_read(unsigned char* ring, uint32_t pos, QPath&
 // [4] T-wave loop iterations  [5] exchanges  [6] lanes pushed  [7] inner steps  [8] lanes active in them  [9] leaf steps
 // [10] lanes active in them  [11] shade batches  [12] reruns on the caller's tree  [13] lanes in shade batches
 // [14] start batches  [15] T-wave iterations that found the wave empty
-template <int RES, bool STATS, int SPEC>
+// RES as in trace_kernel_v2 (0 global memory, 1 LDS, 2 LDS + octant tables, 3 global memory + top of the tree in LDS).
+// POSTPONE (internal tree, scenes in global memory): a lane that reaches a leaf sets it aside and goes on with its next stack entry;
+// the burst is v2's for that case, two rounds of 3 inner steps + 1 leaf step (pt_api.hip: pick_kernel has the measurements).
+template <int RES, bool STATS, int SPEC, bool POSTPONE = false>
 __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev scn, RenderDev rp, LdsPlan lp, QParams q,
                                                                       float4* __restrict__ samples,
                                                                       uint32_t* __restrict__ work_counter,
@@ -228,14 +233,16 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
     unsigned char* shade_ring = smem + q.shade_off;
     unsigned char* ready_ring = smem + q.ready_off;
     // control words and entry flags start at zero; feeds_open = the S-waves
-    for (uint32_t i = threadIdx.x; i < (kQCtlBytes + 2 * kQRing * kQEntryBytes) / 4; i += blockDim.x) {
+    const uint32_t rl = q.ring_log2, ring_n = 1u << rl;
+    for (uint32_t i = threadIdx.x; i < (kQCtlBytes + 2 * ring_n * kQEntryBytes) / 4; i += blockDim.x) {
         // the control area and the two rings are contiguous (pt_api.hip: make_plan_q)
         ((lds_u32*)(smem + q.ctl_off))[i] = (i == (uint32_t)kQFeedsOpen) ? (uint32_t)kQS : 0u;
     }
     const ptd::SceneView sv = make_scene_view<RES>(scn, lp, smem);      // stages the scene; ends with a __syncthreads()
 
     constexpr bool TRI_ONLY = SPEC >= 1, DIFFUSE_ONLY = SPEC >= 2;
-    using STK = int16_t;                                              // LDS-resident scenes only
+    using STK = typename std::conditional<RES == 1 || RES == 2, int16_t, int32_t>::type;     // as v2: 16-bit references where the scene is small
+    constexpr int TOP = RES == 3 ? 1 : 0;
     constexpr int32_t DONE = ptd::done_value<STK>();
     const bool fbk = scn.fallback != 0;
     unsigned long long idle_since = 0;       // wall clock (100 MHz) when this wave last ran out of things to do; 0 = it is busy
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
         tv.inv = ptm::mk(1, 1, 1);
         tv.best.t = 0; tv.best.u = 0; tv.best.v = 0; tv.best.prim = -1;
         tv.cur = DONE; tv.sp = 1; tv.node_off = 0; tv.redo = false;
+        int32_t pend = DONE;                    // POSTPONE: the leaf set aside
         // what the lane only carries from ring to ring
         ptm::V3 cL = ptm::mk(0, 0, 0), cT = ptm::mk(1, 1, 1);
         ptm::Pcg crng;
@@ -262,31 +270,68 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
         uint32_t cdepth = 0, cw = 0;
         for (;;) {
             if (STATS) dg[0]++;
-            // ---- traversal burst: 6 inner steps, 2 leaf steps (the shape v2 uses for LDS-resident scenes)
+            // ---- traversal burst: 6 inner + 2 leaf steps (the shape v2 uses for LDS-resident scenes), or — POSTPONE — two rounds of
+            // 3 inner steps + 1 leaf step with leaves set aside
+            if (POSTPONE) {
 #pragma unroll
-            for (int k = 0; k < PT_Q_BURST_IN; k++) {
-                if (STATS) {
-                    const int n_in = __popcll(__ballot(tv.cur >= 0));
-                    if (n_in) { dg[3]++; dg[4] += (unsigned)n_in; }
-                }
-                if (tv.cur >= 0) {
-                    if (STATS) st.nodes++;
-                    ptd::inner_step<false, RES == 2, STK, 0>(sv, ray.org, tv, stk);
-                }
-            }
+                for (int r = 0; r < 2; r++) {
 #pragma unroll
-            for (int k = 0; k < PT_Q_BURST_LF; k++) {
-                if (STATS) {
-                    const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != DONE));
-                    if (n_lf) { dg[5]++; dg[6] += (unsigned)n_lf; }
+                    for (int k = 0; k < 3; k++) {
+                        if (STATS) {
+                            const int n_in = __popcll(__ballot(tv.cur >= 0));
+                            if (n_in) { dg[3]++; dg[4] += (unsigned)n_in; }
+                        }
+                        if (tv.cur >= 0) {
+                            if (STATS) st.nodes++;
+                            ptd::inner_step<false, false, STK, TOP>(sv, ray.org, tv, stk);
+                            if (tv.cur < 0 && tv.cur != DONE && pend == DONE) {       // a leaf: set it aside, take the next entry
+                                pend = tv.cur;
+                                tv.sp--;
+                                tv.cur = stk[tv.sp * 64];
+                            }
+                        }
+                    }
+                    if (STATS) {
+                        const int n_lf = __popcll(__ballot(pend != DONE));
+                        if (n_lf) { dg[5]++; dg[6] += (unsigned)n_lf; }
+                    }
+                    if (pend != DONE) {
+                        if (STATS) st.leaves++;
+                        ptd::leaf_test<TRI_ONLY>(sv, ray, tv, pend, fbk);
+                        pend = DONE;
+                        if (tv.cur < 0 && tv.cur != DONE) {                           // the lane was blocked on a second leaf
+                            pend = tv.cur;
+                            tv.sp--;
+                            tv.cur = stk[tv.sp * 64];
+                        }
+                    }
                 }
-                if (tv.cur < 0 && tv.cur != DONE) {
-                    if (STATS) st.leaves++;
-                    ptd::leaf_step<STK, TRI_ONLY, false>(sv, ray, tv, stk, false, fbk);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PT_Q_BURST_IN; k++) {
+                    if (STATS) {
+                        const int n_in = __popcll(__ballot(tv.cur >= 0));
+                        if (n_in) { dg[3]++; dg[4] += (unsigned)n_in; }
+                    }
+                    if (tv.cur >= 0) {
+                        if (STATS) st.nodes++;
+                        ptd::inner_step<false, RES == 2, STK, TOP>(sv, ray.org, tv, stk);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PT_Q_BURST_LF; k++) {
+                    if (STATS) {
+                        const int n_lf = __popcll(__ballot(tv.cur < 0 && tv.cur != DONE));
+                        if (n_lf) { dg[5]++; dg[6] += (unsigned)n_lf; }
+                    }
+                    if (tv.cur < 0 && tv.cur != DONE) {
+                        if (STATS) st.leaves++;
+                        ptd::leaf_step<STK, TRI_ONLY, false>(sv, ray, tv, stk, false, fbk);
+                    }
                 }
             }
             // ---- exchange with the rings
-            const bool fin = has && tv.cur == DONE;
+            const bool fin = has && tv.cur == DONE && (!POSTPONE || pend == DONE);
             const unsigned long long fin_m = __ballot(fin);
             const int n_fin = __popcll(fin_m);
             const int n_emp = __popcll(__ballot(!has));
@@ -304,7 +349,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                 if (STATS) dg[1]++;
                 if (do_push) {
                     uint32_t pos;
-                    if (q_reserve(ctl + kQsHead, (uint32_t)n_fin, lane, pos)) {
+                    if (q_reserve(ctl + kQsHead, (uint32_t)n_fin, lane, pos, ring_n)) {
                         if (fin) {
                             QPath p;
                             p.org = ray.org; p.dir = ray.dir;
@@ -312,7 +357,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                             p.L = cL; p.T = cT; p.rng = crng;
                             p.depth_flags = cdepth | (tv.redo ? kQRedoBit : 0u);
                             p.my_w = cw;
-                            q_write(shade_ring, pos + lane_rank(fin_m), p, ctl);
+                            q_write(shade_ring, pos + lane_rank(fin_m), p, ctl, rl);
                             has = false;
                         }
                         if (STATS) dg[2] += (unsigned)n_fin;
@@ -324,7 +369,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                 if (want && r_avail) got = q_claim(ctl + kQrHead, want, 1u, lane, pos);
                 if (!has && lane_rank(emp_m) < got) {
                     QPath p;
-                    q_read(ready_ring, pos + lane_rank(emp_m), p, ctl);
+                    q_read(ready_ring, pos + lane_rank(emp_m), p, ctl, rl);
                     ray.org = p.org; ray.dir = p.dir;
                     cL = p.L; cT = p.T; crng = p.rng; cdepth = p.depth_flags & 0xffffu; cw = p.my_w;
                     const bool primary = cdepth == 0u;
@@ -342,7 +387,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                     has = true;
                     n_segs++;
                 }
-                if (__ballot(has && tv.cur != DONE) == 0ull) {
+                if (__ballot(has && !(tv.cur == DONE && (!POSTPONE || pend == DONE))) == 0ull) {
                     // nothing to traverse (lanes are empty, or hold finished paths the shade ring has no room for yet):
                     // finished, or wait for the S-waves — never longer than the watchdog allows
                     if (STATS) dg[11]++;
@@ -374,7 +419,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
             bool did = false;
             // ---- start paths (main.cu:32-44) while the workgroup is below its target
             if (feed_open && (int32_t)q_load(ctl + kQLive) + 64 <= q.target &&
-                q_load(ctl + kQrTail) - q_load(ctl + kQrHead) + 64u <= kQRing) {
+                q_load(ctl + kQrTail) - q_load(ctl + kQrHead) + 64u <= ring_n) {
                 feed_reserve(feed, rp, work_counter, lane);
                 const uint32_t avail = feed.end - feed.cur;
                 if (avail == 0) {
@@ -408,9 +453,9 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                             p.my_w = ps.sample_index;
                         }
                         uint32_t pos = 0;
-                        if (q_reserve(ctl + kQrHead, n, lane, pos)) {
+                        if (q_reserve(ctl + kQrHead, n, lane, pos, ring_n)) {
                             if ((uint32_t)lane < n) {
-                                q_write(ready_ring, pos + (uint32_t)lane, p, ctl);
+                                q_write(ready_ring, pos + (uint32_t)lane, p, ctl, rl);
                                 n_paths++;
                             }
                             feed.cur += n;
@@ -437,7 +482,7 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                     p.L = ptm::mk(0, 0, 0); p.T = ptm::mk(1, 1, 1); p.rng.state = 0; p.rng.inc = 1; p.depth_flags = 0; p.my_w = 0;
                     bool cont = false;
                     if (mine) {
-                        q_read(shade_ring, pos + (uint32_t)lane, p, ctl);
+                        q_read(shade_ring, pos + (uint32_t)lane, p, ctl, rl);
                         ptd::Ray ray;
                         ray.org = p.org; ray.dir = p.dir;
                         int depth = (int)(p.depth_flags & 0xffffu);
@@ -485,11 +530,11 @@ __global__ __launch_bounds__(kQBlock, PT_Q_MINW) void trace_kernel_q(SceneDev sc
                         // never holds more paths than fit (q.target), so this wait ends
                         uint32_t rpos = 0, spins = 0;
                         bool placed;
-                        while (!(placed = q_reserve(ctl + kQrHead, n_cont, lane, rpos))) {
+                        while (!(placed = q_reserve(ctl + kQrHead, n_cont, lane, rpos, ring_n))) {
                             if (++spins > kQSpinLimit || q_load(ctl + kQError) != 0u) { q_flag_error(ctl); break; }
                             __builtin_amdgcn_s_sleep(2);
                         }
-                        if (placed && mine && cont) q_write(ready_ring, rpos + lane_rank(cont_m), p, ctl);
+                        if (placed && mine && cont) q_write(ready_ring, rpos + lane_rank(cont_m), p, ctl, rl);
                     }
                 }
             }

@@ -72,8 +72,7 @@ def test_random_scenes_all_materials_regrouped(oracle, seed):
     try:
         img = ds.render(p)
         c = ds.counters()
-        if ds.info("lds_scene"):
-            assert ds.info("kernel") == 3
+        assert ds.info("kernel") == 3
         assert_bit_equal(img, want, f"random scene {seed}")
         assert (c.paths, c.segments) == (cnt.paths, cnt.segments)
     finally:
@@ -81,7 +80,7 @@ def test_random_scenes_all_materials_regrouped(oracle, seed):
 
 
 def test_what_the_regrouped_kernel_does_not_serve_runs_on_kernel_2(oracle):
-    """Pruned traversal, next-event estimation and scenes in global memory keep to kernel 2 under option kernel = 3."""
+    """Pruned traversal and next-event estimation keep to kernel 2 under option kernel = 3."""
     from pathtracer_cuda_interactive_amd import PT_RENDER_NEE
     hs, d = load_scene("cbox")
     p = hs.render_params(64, 48, 4)
@@ -95,21 +94,37 @@ def test_what_the_regrouped_kernel_does_not_serve_runs_on_kernel_2(oracle):
         q.flags = PT_RENDER_NEE
         ds.render(q)
         assert ds.info("kernel") == 2
-        ds.set_option("force_global", 1)
-        assert_bit_equal(ds.render(p), want, "cbox from global memory")
-        assert ds.info("kernel") == 2
-        ds.set_option("force_global", 0)
         assert_bit_equal(ds.render(p), want, "cbox back on kernel 3")
         assert ds.info("kernel") == 3
     finally:
         ds.close()
-    hs, d = load_scene("teapot")
-    p = hs.render_params(50, 40, 3)
-    want, _ = oracle.render(d, p)
-    ds = q_scene(d)
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("teapot", 50, 40, 3), ("bunny", 40, 30, 2), ("cbox", 64, 48, 4)])
+def test_regrouped_kernel_on_scenes_in_global_memory(oracle, name, w, h, spp):
+    """Scenes read from global memory (cbox: forced there): 32-bit stacks, the top of the tree in LDS, leaves set aside on the internal
+    tree, rings of half the size — on the internal tree, on the caller's tree, and without the top-of-tree cache."""
+    hs, d = load_scene(name)
+    p = hs.render_params(w, h, spp, seed=77)
+    want, cnt = oracle.render(d, p)
+    ds = q_scene(d, stats=1)
     try:
-        assert_bit_equal(ds.render(p), want, "teapot")
-        assert ds.info("kernel") == 2
+        if name == "cbox":
+            ds.set_option("force_global", 1)
+        img = ds.render(p)
+        c = ds.counters()
+        assert ds.info("kernel") == 3 and ds.info("lds_scene") == 0
+        assert_bit_equal(img, want, name)
+        assert_work_counters(ds, c, cnt, oracle, d, p, name)
+        ds.set_option("top_cache", 0)
+        assert_bit_equal(ds.render(p), want, name + " without the top-of-tree cache")
+        ds.set_option("top_cache", 1)
+        ds.set_option("fast_tree", 0)
+        img = ds.render(p)
+        c = ds.counters()
+        assert_bit_equal(img, want, name + " caller's tree")
+        assert (c.node_visits, c.leaf_tests) == (cnt.inner_pops, cnt.leaf_tri + cnt.leaf_sphere)
+        assert ds.info("kernel") == 3
     finally:
         ds.close()
 

@@ -43,6 +43,10 @@ for k in range(n):
         c0 = ds.counters()
         ok = ok and bool((img0.view(np.uint32) == want.view(np.uint32)).all())
         ok = ok and (c0.node_visits, c0.leaf_tests) == (cnt.inner_pops, cnt.leaf_tri + cnt.leaf_sphere)
+        ds.set_option("fast_tree", 1)
+        ds.set_option("kernel", 3)                        # ... and the regrouped kernel on a scene in global memory
+        img3 = ds.render(p)
+        ok = ok and ds.info("kernel") == 3 and bool((img3.view(np.uint32) == want.view(np.uint32)).all())
         ds.close()
         _, th = dev.build_bvh_sweep(d)
         try:
