@@ -19,7 +19,7 @@ for it in range(n):
     name = list(scenes)[it % len(scenes)]
     hs, ds = scenes[name]
     w, h, spp = [(160, 120, 4), (97, 61, 7), (320, 240, 2), (64, 64, 16)][(it // 5) % 4]
-    kernel = 2 if (it // 20) % 3 else 1
+    kernel = [2, 1, 3, 2, 3][(it // 20) % 5]            # 3 = paths regrouped across waves (round 3): same frames
     trav = PT_TRAVERSAL_EXACT
     stride = [1, 3, 8][(it // 7) % 3]
     ds.set_option("kernel", kernel)
@@ -30,6 +30,8 @@ for it in range(n):
     ds.set_option("item_order", (it // 23) % 2)
     ds.set_option("chunk", [0, 64, 128, 256][(it // 29) % 4])
     ds.set_option("lds_budget_kb", [0, 24, 39][(it // 31) % 3])
+    ds.set_option("q_swap", [0, 4, 32][(it // 43) % 3])
+    ds.set_option("q_target", [0, 200, 100000][(it // 47) % 3])
     ds.set_option("fast_tree", 0 if (it // 41) % 3 == 2 else 1)      # internal or caller's tree: the frame must not care
     nee = kernel == 2 and (it // 37) % 2 == 1
     p = hs.render_params(w, h, spp)
