@@ -372,6 +372,8 @@ def main():
     kernel_ms, resolve_ms = R.scene.frame_times(args.steps)
     if len(kernel_ms) != args.steps:
         raise SystemExit("bench.py: the library did not keep the events of every timed frame")
+    if os.environ.get("PT_BENCH_DUMP_FRAMES") and rank == 0:
+        sys.stderr.write("kernel_ms per timed frame: " + " ".join(f"{t:.3f}" for t in kernel_ms) + "\n")
     segs = [c_last.segments] * args.steps
     paths = [c_last.paths] * args.steps
 
@@ -418,7 +420,15 @@ def main():
                 traffic = int(traffic * passes)         # "launch" here = one frame = `passes` trace_kernel launches
         lds_scene = bool(R.scene.info("lds_scene"))
         # flat scalars from the committed rocprofv3 PMC run of this config (profiles/, tools/profile_gpu.sh) and this run's kernel time
-        physical = {} if stub else physical_roofline(args.scene, args.traversal, lds_scene, k_ms, passes)
+        # Frames in flight (the library's default: 2): the trace kernel of frame k+1 starts while the last paths of frame k drain,
+        # so a launch's HIP-event duration includes the time its blocks waited for the previous launch's to leave the CUs and the
+        # durations of consecutive launches overlap.  `achieved` / `frac` keep that duration (per-launch duration);
+        # the physical fraction is counted against the time the chip really spent per frame: the wall time of a step.
+        in_flight = 1 if stub else int(R.scene.info("frames_in_flight"))
+        overlapped = in_flight > 1 and passes == 1
+        physical = {} if stub else physical_roofline(args.scene, args.traversal, lds_scene, ms_per_step if overlapped else k_ms, passes)
+        if physical and overlapped:
+            physical["physical_time_base"] = "ms_per_step (launches of consecutive frames overlap: frames_in_flight)"
         work_done_frac = None
         if work and "callers_tree_inner_visits_per_segment" in work:
             # "work avoided is not bandwidth achieved" (SURVEY §8d): the algorithmic figure with the inner visits this run really
@@ -462,7 +472,7 @@ def main():
                        # same closest hits (ties in the caller's visit order), fewer inner visits; "caller" = --tree caller
                        "tree": ("stub" if stub else "internal" if R.scene.info("fast_tree_on") else "caller"),
                        "stack_entries": 0 if stub else int(R.scene.info("stack_entries")),
-                       "host_sync_per_step": False, "forced_gather": force_gather,
+                       "host_sync_per_step": False, "forced_gather": force_gather, "frames_in_flight": in_flight,
                        "work": work,
                        "frame_mean": round(float(frame.mean().item()), 6)},
             "roofline": roofline,

@@ -184,7 +184,13 @@ int pt_scene_destroy(pt_scene* scene);
 int pt_render(pt_scene* scene, const pt_render_params* p, float* fb, int fb_on_device);
 
 /* Same, enqueued on a caller-provided hipStream_t (NULL = default stream); fb
- * must be a device pointer; returns without synchronising. */
+ * must be a device pointer; returns without synchronising.  What the caller can
+ * observe — fb, and accum_dev below — is written in the order of that stream.  The
+ * trace kernel itself reads only the scene and writes scratch memory of the handle,
+ * so with "frames_in_flight" > 1 (option, default 2) a frame runs on a stream of the
+ * handle's own — its resolve behind an event of the caller's stream, the caller's
+ * stream behind its resolve — and the trace kernel of call k+1 fills the compute
+ * units while the last paths of call k drain; same bits either way. */
 int pt_render_async(pt_scene* scene, const pt_render_params* p, float* fb_dev, void* hip_stream);
 
 /* Progressive accumulation (render_progressive, main.cu:64-89): adds the SUM
@@ -255,6 +261,10 @@ int pt_bvh_build_sweep_device(const pt_scene_desc* desc, pt_bvh_node* out_nodes,
  *   "force_global"  1 = never stage the scene in LDS
  *   "blocks_per_cu" persistent blocks per CU (0 = occupancy query; at most 32)
  *   "timing_frames" render calls whose HIP events are kept for pt_get_frame_times (1 .. 4096, default 1)
+ *   "frames_in_flight" 1 .. 4 (default 2): sets of per-frame scratch memory (per-sample buffer, work and statistics counters)
+ *                   the handle rotates through; with more than one, consecutive render calls overlap as described at
+ *                   pt_render_async (frames that need several sample passes run on the caller's stream as with 1).
+ *                   kernel_ms of a frame that overlapped with its neighbours includes the time its blocks waited for theirs.
  *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 8 GiB); larger jobs run in sample passes
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the
  *                   launch timeline ("diag8".."diag15", 10-ns ticks; "diag16".."diag271" per-wave histograms; tools/gpu_diag.py)
@@ -264,7 +274,7 @@ int pt_bvh_build_sweep_device(const pt_scene_desc* desc, pt_bvh_node* out_nodes,
  * topology in internal form: the sweep tree did not win the probe), "fast_tree_depth",
  * "fast_tree_cost_permille" (probe-ray node visits, internal / caller's x 1000; 0 = none built), "stack_entries" (per lane),
  * "redo_segments" (with "stats": segments of the last frame traced on the caller's tree), "debug_reruns" (same for pt_debug_intersect),
- * "kernel" / "block_threads" (what the last render ran on), "sweep_on_device" (the internal tree was built on the GPU),
+ * "kernel" / "block_threads" (what the last render ran on), "frames_in_flight", "sweep_on_device" (the internal tree was built on the GPU),
  * "create_us0".."create_us6" (wall microseconds of pt_scene_create: total, primitive records, caller's tree checked and re-laid,
  * internal tree built, ... re-laid, uploads + probe, tie tables). */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);

@@ -104,6 +104,11 @@ constexpr uint32_t kTopNodes = PT_TOP_NODES;              // scenes read from gl
 #endif
 constexpr uint32_t kTopLdsBudget = PT_TOP_LDS_KB * 1024;    // LDS per block that keeps 6 blocks per CU resident (160 KB / 6)
 constexpr uint32_t kMaxLdsBudget = 160 * 1024;               // the breadth-first numbered prefix is sized for the largest budget an option may ask for
+constexpr int kMaxFramesInFlight = 4;            // frame slots a handle may hold (option frames_in_flight)
+#ifndef PT_FRAMES_IN_FLIGHT
+#define PT_FRAMES_IN_FLIGHT 2
+#endif
+constexpr int kDefaultFramesInFlight = PT_FRAMES_IN_FLIGHT;
 constexpr size_t kWorkBytes = 8 * kCounterStride * sizeof(uint32_t);   // 8 band counters, one 128-B line each
 constexpr size_t kWorkWords = kWorkBytes / sizeof(unsigned long long);
 
@@ -155,7 +160,6 @@ struct pt_scene {
     DevBuf<int32_t> ref_anc;         // per primitive and level: the inner node of the caller's tree there
     int32_t ref_levels = 0;
     bool fast_is_callers_topology = false;   // tree[1] = the caller's own tree in internal form (the sweep tree did not win)
-    DevBuf<int32_t> redo_stack;      // global-memory traversal stacks of the reference-order reruns (one column per lane of the grid)
     DevBuf<DPrim> prims;
     DevBuf<DNormals> normals;
     DevBuf<DMaterial> materials;
@@ -166,13 +170,42 @@ struct pt_scene {
     bool tri_only = false;           // the scene holds no sphere
     bool diffuse_only = false;       // every material is DIFFUSE
     // scratch
-    DevBuf<float4> samples;
     DevBuf<float> accum;
     DevBuf<float> fb_tmp;
-    // control block: [0, kWorkBytes) the band work counters, then the statistics (kNumCounters uint64, pt_kernels.h)
-    DevBuf<unsigned long long> ctl;
-    uint32_t* work_counter() const { return reinterpret_cast<uint32_t*>(ctl.p); }
-    unsigned long long* counters() const { return ctl.p ? ctl.p + kWorkWords : nullptr; }
+    // What a frame's trace kernel writes lives in a frame slot; render call k uses slot k % frames_in_flight.  With more than one
+    // slot a single-pass frame runs on the slot's own stream: the trace kernel at once (it reads the immutable scene and writes
+    // the slot only), the resolve — the one step that touches the caller's buffer — once the caller's stream has reached the
+    // point of the call (in_ev), and the caller's stream continues behind the resolve (free_ev).  The next frame's trace kernel
+    // then fills the CUs while this one's last paths drain (the tail of a persistent launch is a partly empty chip), and
+    // everything the caller can observe stays in the order of the caller's stream.  Both waits across streams sit beside the
+    // chain trace k -> resolve k -> trace k + slots, which is in order on ONE stream (an event wait across streams costs tens of
+    // microseconds on this runtime; with the resolve on the caller's stream, two of them per frame sat on that chain and
+    // two slots rendered slower than one).  A slot is reused once the resolve that read its samples has finished (free_ev).
+    struct FrameSlot {
+        DevBuf<float4> samples;
+        // control block: [0, kWorkBytes) the band work counters, then the statistics (kNumCounters uint64, pt_kernels.h)
+        DevBuf<unsigned long long> ctl;
+        DevBuf<int32_t> redo_stack;  // global-memory traversal stacks of the reference-order reruns (one column per lane of the grid)
+        hipStream_t stream = nullptr;
+        hipEvent_t free_ev = nullptr, in_ev = nullptr;
+        hipStream_t free_stream = nullptr;   // the stream free_ev was last recorded on
+        bool used = false;
+    } slot[kMaxFramesInFlight];
+    int cur_slot = 0;                // the slot of the last render call
+    int64_t opt_frames_in_flight = kDefaultFramesInFlight;
+    FrameSlot& cur() { return slot[cur_slot]; }
+    const FrameSlot& cur() const { return slot[cur_slot]; }
+    uint32_t* work_counter() const { return reinterpret_cast<uint32_t*>(cur().ctl.p); }
+    unsigned long long* counters() const { return cur().ctl.p ? cur().ctl.p + kWorkWords : nullptr; }
+    void drop_slots() {
+        for (auto& f : slot) {
+            f.samples.release(); f.ctl.release(); f.redo_stack.release();
+            if (f.stream) (void)hipStreamDestroy(f.stream);
+            if (f.free_ev) (void)hipEventDestroy(f.free_ev);
+            if (f.in_ev) (void)hipEventDestroy(f.in_ev);
+            f.stream = nullptr; f.free_ev = nullptr; f.in_ev = nullptr; f.used = false;
+        }
+    }
     hipStream_t last_stream = nullptr;
     bool have_timing = false;
     // options
@@ -197,7 +230,7 @@ struct pt_scene {
     // [3] internal tree built [4] ... re-laid [5] uploads + probe [6] tie tables; built_on_device: the sweep ran on the GPU
     int64_t create_us[7] = {0, 0, 0, 0, 0, 0, 0}, sweep_on_device = 0;
     int64_t info_grid = 0, info_lds_bytes = 0, info_lds_scene = 0, info_passes = 0, info_occupancy = 0, info_blocks_per_cu = 0, info_debug_reruns = 0, fast_cost_permille = 0, info_kernel = 0;
-    struct PassEvents { hipEvent_t t0, t1, r1; };                // trace begin, trace end = resolve begin, resolve end
+    struct PassEvents { hipEvent_t t0, t1, r0, r1; };            // trace begin, trace end (on the trace kernel's stream); resolve begin, end (caller's)
     // HIP events of the last `opt_timing_frames` render calls (a ring; default 1): a caller that enqueues frame after frame
     // without a host sync in between — bench.py's timed loop — reads every frame's kernel time afterwards (pt_get_frame_times)
     struct FrameRec { std::vector<PassEvents> ev; size_t passes = 0; };
@@ -207,7 +240,7 @@ struct pt_scene {
     const FrameRec* last_frame() const { return frame_seq && !frames.empty() ? &frames[(frame_seq - 1) % frames.size()] : nullptr; }
     void drop_events() {
         for (auto& f : frames)
-            for (auto& pe : f.ev) { (void)hipEventDestroy(pe.t0); (void)hipEventDestroy(pe.t1); (void)hipEventDestroy(pe.r1); }
+            for (auto& pe : f.ev) { (void)hipEventDestroy(pe.t0); (void)hipEventDestroy(pe.t1); (void)hipEventDestroy(pe.r0); (void)hipEventDestroy(pe.r1); }
         frames.clear();
         frame_seq = 0;
     }
@@ -233,7 +266,7 @@ void select_tree(pt_scene* S, int which, bool fallback = false) {
     dv.ref_nodes = S->tree[0].nodes.p;
     dv.ref_root_ref = S->tree[0].root_ref;
     dv.redo_cap = S->tree[0].stack_cap;
-    dv.redo_stack = S->redo_stack.p;
+    dv.redo_stack = S->cur().redo_stack.p;
     dv.fixed_order = which == 1 ? 1 : 0;
     dv.ref_path = S->ref_path.p;
     dv.ref_anc = S->ref_anc.p;
@@ -733,6 +766,9 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
             S->ref_levels = levels;
         }
     }
+    // everything the scene holds is complete from here on: trace kernels run on streams of the handle's own (FrameSlot) that do
+    // not synchronise with the stream the preparation kernels ran on
+    HIP_TRY(hipDeviceSynchronize());
     S->create_us[6] = us_since(t_stage);
     S->create_us[0] = us_since(t_all);
     select_tree(S, 0);
@@ -981,9 +1017,20 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     if (rc) return rc;
     DeviceGuard guard;
     { int grc = guard.enter(S->device); if (grc) return grc; }
-    if ((rc = S->ctl.ensure(kWorkWords + kNumCounters))) return rc;
-    // one memset per frame: work counters + the 64 counter slots (+ timeline / histograms when a STATS kernel will run)
-    HIP_TRY(hipMemsetAsync(S->ctl.p, 0, (kWorkWords + (S->opt_stats ? kNumCounters : kTimelineBase)) * sizeof(unsigned long long), stream));
+    // this call's frame slot (see pt_scene::FrameSlot)
+    const int in_flight = (int)std::min<int64_t>(kMaxFramesInFlight, std::max<int64_t>(1, S->opt_frames_in_flight));
+    // Is the previous call's frame still on the GPU?  If not there is nothing to overlap with, and this frame runs on the
+    // caller's stream as with one slot: a caller that synchronises after every frame (a display loop) does not pay for two
+    // event waits across streams per frame.
+    bool prev_busy = false;
+    if (in_flight > 1 && S->frame_seq > 0 && S->cur().used) {
+        prev_busy = hipEventQuery(S->cur().free_ev) == hipErrorNotReady;
+        (void)hipGetLastError();
+    }
+    S->cur_slot = (int)(S->frame_seq % (uint64_t)in_flight);
+    pt_scene::FrameSlot& slot = S->cur();
+    if ((rc = slot.ctl.ensure(kWorkWords + kNumCounters))) return rc;
+    if (!slot.free_ev) HIP_TRY(hipEventCreateWithFlags(&slot.free_ev, hipEventDisableTiming));
     S->last_stream = stream;
     S->have_timing = false;
     S->info_passes = 0;
@@ -994,25 +1041,31 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     pt_scene::FrameRec& frec = S->frames[S->frame_seq % S->frames.size()];
     frec.passes = 0;
     S->frame_seq++;
-    if (rows.count == 0) return PT_OK;
+    if (rows.count == 0) {           // nothing to trace: the frame's counters read zero
+        if (slot.used && slot.free_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, slot.free_ev, 0));
+        HIP_TRY(hipMemsetAsync(slot.ctl.p, 0, (kWorkWords + kTimelineBase) * sizeof(unsigned long long), stream));
+        HIP_TRY(hipEventRecord(slot.free_ev, stream));
+        slot.used = true; slot.free_stream = stream;
+        return PT_OK;
+    }
 
     const uint64_t npix = (uint64_t)rows.count * (uint64_t)p->width;
     if (npix > (1ull << 30)) return fail(PT_ERR_INVALID_ARG, "more than 2^30 pixels per call");
     // samples per pass: bounded by the scratch budget and by 2^30 work items per launch
     uint64_t scratch = S->opt_scratch_bytes > 0 ? (uint64_t)S->opt_scratch_bytes : kDefaultScratchBytes;
-    if (S->opt_scratch_bytes <= 0 && std::min<uint64_t>(scratch, npix * (uint64_t)p->spp * sizeof(float4)) > S->samples.n * sizeof(float4)) {
+    if (S->opt_scratch_bytes <= 0 && std::min<uint64_t>(scratch, npix * (uint64_t)p->spp * sizeof(float4)) > slot.samples.n * sizeof(float4)) {
         // the buffer must grow under the default budget: never to more than a quarter of what is free on the device right
         // now, so that several handles / ranks on one GPU, or a smaller GPU, split into more passes instead of failing
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            scratch = std::min<uint64_t>(scratch, std::max<uint64_t>((uint64_t)free_b / 4, S->samples.n * sizeof(float4)));
+            scratch = std::min<uint64_t>(scratch, std::max<uint64_t>((uint64_t)free_b / 4, slot.samples.n * sizeof(float4)));
     }
     uint64_t spp_pass = std::max<uint64_t>(1, std::min<uint64_t>(scratch / (npix * sizeof(float4)), (1ull << 30) / npix));
     spp_pass = std::min<uint64_t>(spp_pass, (uint64_t)p->spp);
     if (mode == 2 && spp_pass < (uint64_t)p->spp)
         return fail(PT_ERR_UNSUPPORTED, "pt_render_accumulate: spp of one call must fit the scratch budget (single pass)");
     // allocation failure (another handle took the memory meanwhile): halve the samples per pass and retry
-    while ((rc = S->samples.ensure(npix * spp_pass))) {
+    while ((rc = slot.samples.ensure(npix * spp_pass))) {
         if (spp_pass == 1 || mode == 2) return rc;
         (void)hipGetLastError();
         spp_pass = (spp_pass + 1) / 2;
@@ -1079,10 +1132,36 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         // is a caller's option and the kernel indexes the buffer by blockIdx (pt_kernels.h: redo_stk).
         const size_t lanes = use_q ? (size_t)launch_grid(S->num_cus, bpc, npix * spp_pass, kQBlock) * kQS * 64    // S-waves rerun
                                    : redo_stack_lanes(S->num_cus, bpc, npix * spp_pass);
-        if ((rc = S->redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
+        if ((rc = slot.redo_stack.ensure(lanes * (size_t)S->tree[0].stack_cap))) return rc;
     }
     select_tree(S, which, which == 1);
     float* accum = mode == 2 ? out_dev : S->accum.p;
+    // Single-pass frames of a handle with more than one slot run on the slot's stream (pt_scene::FrameSlot)
+    const bool own_stream = in_flight > 1 && n_pass == 1 && prev_busy;
+    hipStream_t tstream = stream;
+    if (own_stream) {
+        if (!slot.stream) {
+            // A stream of the lowest priority: the runtime maps streams onto a few hardware queues PER PRIORITY (4 by default),
+            // and two streams on one hardware queue run in order.  Among the application's own normal-priority streams the two
+            // slot streams ended up sharing a queue with each other or with the caller's as often as not (one more stream in
+            // the process: 2.70 ms per cbox frame with two slots against 2.69 with one; on queues of their own 2.53 —
+            // profiles/r03_frames_in_flight.log).  Low rather than high: a frame waits for the caller's other GPU work (the
+            // RCCL gather of the rank's rows, N > 1), not the other way round.  PT_SLOT_STREAM_PRIORITY=normal|high: A/B runs.
+            const char* pr = std::getenv("PT_SLOT_STREAM_PRIORITY");
+            const std::string want = pr ? pr : "low";
+            int least = 0, greatest = 0;
+            if (want != "normal" && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                HIP_TRY(hipStreamCreateWithPriority(&slot.stream, hipStreamNonBlocking, want == "high" ? greatest : least));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+        }
+        if (!slot.in_ev) HIP_TRY(hipEventCreateWithFlags(&slot.in_ev, hipEventDisableTiming));
+        tstream = slot.stream;
+        HIP_TRY(hipEventRecord(slot.in_ev, stream));
+    }
+    if (slot.used && slot.free_stream != tstream) HIP_TRY(hipStreamWaitEvent(tstream, slot.free_ev, 0));   // the resolve that last read this slot's samples
+    // one memset per frame: work counters + the 64 counter slots (+ timeline / histograms when a STATS kernel will run)
+    HIP_TRY(hipMemsetAsync(slot.ctl.p, 0, (kWorkWords + (S->opt_stats ? kNumCounters : kTimelineBase)) * sizeof(unsigned long long), tstream));
     for (int pass = 0; pass < n_pass; pass++) {
         const int s0 = pass * (int)spp_pass;
         const int sn = std::min<int>((int)spp_pass, p->spp - s0);
@@ -1114,7 +1193,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         }
 
         const int grid = launch_grid(S->num_cus, bpc, rd.total_work, block_threads);
-        if (which == 1 && (size_t)grid * (use_q ? kQS * 64 : kBlock) * (size_t)S->tree[0].stack_cap > S->redo_stack.n)
+        if (which == 1 && (size_t)grid * (use_q ? kQS * 64 : kBlock) * (size_t)S->tree[0].stack_cap > slot.redo_stack.n)
             return fail(PT_ERR_DEVICE, "internal error: rerun stacks smaller than the grid");
         S->info_grid = grid;
         // chunk: work items a wave reserves per atomic.  Big launches (a wave traces >= 2048 items): 128 — the waves of a
@@ -1131,21 +1210,24 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
             pt_scene::PassEvents fresh{};
             hipError_t ee = hipEventCreate(&fresh.t0);
             if (ee == hipSuccess && (ee = hipEventCreate(&fresh.t1)) != hipSuccess) (void)hipEventDestroy(fresh.t0);
-            if (ee == hipSuccess && (ee = hipEventCreate(&fresh.r1)) != hipSuccess) { (void)hipEventDestroy(fresh.t0); (void)hipEventDestroy(fresh.t1); }
+            if (ee == hipSuccess && (ee = hipEventCreate(&fresh.r0)) != hipSuccess) { (void)hipEventDestroy(fresh.t0); (void)hipEventDestroy(fresh.t1); }
+            if (ee == hipSuccess && (ee = hipEventCreate(&fresh.r1)) != hipSuccess) { (void)hipEventDestroy(fresh.t0); (void)hipEventDestroy(fresh.t1); (void)hipEventDestroy(fresh.r0); }
             if (ee != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(ee));
             frec.ev.push_back(fresh);
         }
         const pt_scene::PassEvents pe = frec.ev[pass];
-        if (pass > 0) HIP_TRY(hipMemsetAsync(S->ctl.p, 0, kWorkBytes, stream));
-        HIP_TRY(hipEventRecord(pe.t0, stream));
+        if (pass > 0) HIP_TRY(hipMemsetAsync(slot.ctl.p, 0, kWorkBytes, tstream));
+        HIP_TRY(hipEventRecord(pe.t0, tstream));
         if (use_q)
-            hipLaunchKernelGGL(fnq, dim3(grid), dim3(kQBlock), lp.total, stream, S->dev, rd, lp, qp, S->samples.p,
+            hipLaunchKernelGGL(fnq, dim3(grid), dim3(kQBlock), lp.total, tstream, S->dev, rd, lp, qp, slot.samples.p,
                                S->work_counter(), S->counters());
         else
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, stream, S->dev, rd, lp, S->samples.p,
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, tstream, S->dev, rd, lp, slot.samples.p,
                                S->work_counter(), S->counters());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(pe.t1, stream));
+        HIP_TRY(hipEventRecord(pe.t1, tstream));
+        if (own_stream) HIP_TRY(hipStreamWaitEvent(tstream, slot.in_ev, 0));   // the resolve writes the caller's buffer
+        HIP_TRY(hipEventRecord(pe.r0, tstream));
 
         const bool first = pass == 0, last = pass == n_pass - 1;
         int rmode;
@@ -1160,10 +1242,13 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         } else {
             rmode = 1; rfirst = first ? 1 : 0;
         }
-        hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, S->samples.p, accum,
+        hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, tstream, slot.samples.p, accum,
                            out_dev, (uint32_t)npix, sn, rmode, rfirst, scale);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(pe.r1, stream));
+        HIP_TRY(hipEventRecord(pe.r1, tstream));
+        HIP_TRY(hipEventRecord(slot.free_ev, tstream));
+        slot.used = true; slot.free_stream = tstream;
+        if (own_stream) HIP_TRY(hipStreamWaitEvent(stream, slot.free_ev, 0));
         S->info_passes++;
         frec.passes = (size_t)pass + 1;
     }
@@ -1174,7 +1259,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
 // trace_kernel_q bounds every wait on its rings; a wait that ran into its bound leaves a mark in counter slot 15 and an
 // invalid frame behind.  (The stream has been synchronised.)
 int check_schedule_error(const pt_scene* S) {
-    if (S->info_kernel != 3 || !S->ctl.p) return PT_OK;
+    if (S->info_kernel != 3 || !S->cur().ctl.p) return PT_OK;
     unsigned long long c[kSlotStride];
     int rc = read_slot_sums(S, c);
     if (rc) return rc;
@@ -1188,7 +1273,7 @@ int frame_times(const pt_scene::FrameRec& f, double* kernel_ms, double* resolve_
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, f.ev[k].t0, f.ev[k].t1));
         t += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, f.ev[k].t1, f.ev[k].r1));
+        HIP_TRY(hipEventElapsedTime(&ms, f.ev[k].r0, f.ev[k].r1));
         r += ms;
     }
     *kernel_ms = t;
@@ -1230,8 +1315,8 @@ int pt_scene_destroy(pt_scene* S) {
     DeviceGuard guard;
     (void)guard.enter(S->device);
     if (S->last_stream || S->have_timing) (void)hipDeviceSynchronize();
-    for (auto& T : S->tree) { T.nodes.release(); T.nodes_oct.release(); } S->redo_stack.release(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
-    S->lights.release(); S->samples.release(); S->accum.release(); S->fb_tmp.release(); S->ctl.release();
+    for (auto& T : S->tree) { T.nodes.release(); T.nodes_oct.release(); } S->drop_slots(); S->prims.release(); S->normals.release(); S->materials.release(); S->emission.release();
+    S->lights.release(); S->accum.release(); S->fb_tmp.release();
     S->drop_events();
     delete S;
     return PT_OK;
@@ -1273,7 +1358,7 @@ int pt_get_counters(pt_scene* S, pt_counters* out) {
     DeviceGuard guard;
     { int grc = guard.enter(S->device); if (grc) return grc; }
     HIP_TRY(hipStreamSynchronize(S->last_stream));
-    if (!S->ctl.p) return PT_OK;
+    if (!S->cur().ctl.p) return PT_OK;
     unsigned long long c[kSlotStride];
     int rc = read_slot_sums(S, c);
     if (rc) return rc;
@@ -1326,6 +1411,10 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
         S->opt_timing_frames = value;
     }
     else if (k == "kernel") { if (value < 1 || value > 3) return fail(PT_ERR_INVALID_ARG, "kernel must be 1, 2 or 3"); S->opt_kernel = value; }
+    else if (k == "frames_in_flight") {
+        if (value < 1 || value > kMaxFramesInFlight) return fail(PT_ERR_INVALID_ARG, "frames_in_flight must be 1 .. " + std::to_string(kMaxFramesInFlight));
+        S->opt_frames_in_flight = value;
+    }
     else if (k == "q_target") S->opt_q_target = value;
     else if (k == "q_swap") S->opt_q_swap = value;
     else if (k == "q_low") S->opt_q_low = value;
@@ -1351,7 +1440,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
         { int grc = guard.enter(S->device); if (grc) return grc; }
         HIP_TRY(hipStreamSynchronize(S->last_stream));
         unsigned long long c[kSlotStride] = {0};
-        if (S->ctl.p) { int rc = read_slot_sums(S, c); if (rc) return rc; }
+        if (S->cur().ctl.p) { int rc = read_slot_sums(S, c); if (rc) return rc; }
         *value = (int64_t)c[12];
     }
     else if (k == "num_cus") *value = S->num_cus;
@@ -1371,6 +1460,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
     else if (k.rfind("create_us", 0) == 0 && k.size() == 10 && k[9] >= '0' && k[9] <= '6') *value = S->create_us[k[9] - '0'];
     else if (k == "kernel") *value = S->info_kernel;                      // the kernel the last render ran on (1, 2 or 3)
     else if (k == "block_threads") *value = S->info_kernel == 3 ? kQBlock : kBlock;
+    else if (k == "frames_in_flight") *value = S->opt_frames_in_flight;
     else if (k.rfind("qdiag", 0) == 0 && k.size() >= 6 && k.size() <= 7 && k.find_first_not_of("0123456789", 5) == std::string::npos &&
              std::stoi(k.substr(5)) < 11) {
         // schedule diagnostics of the last STATS render of trace_kernel_q: counter slots [4..14], see pt_kernel_q.h
@@ -1378,7 +1468,7 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
         { int grc = guard.enter(S->device); if (grc) return grc; }
         HIP_TRY(hipStreamSynchronize(S->last_stream));
         unsigned long long c[kSlotStride] = {0};
-        if (S->ctl.p) { int rc = read_slot_sums(S, c); if (rc) return rc; }
+        if (S->cur().ctl.p) { int rc = read_slot_sums(S, c); if (rc) return rc; }
         *value = (int64_t)c[4 + std::stoi(k.substr(5))];
     }
     else if (k.rfind("diag", 0) == 0 && k.size() >= 5 && k.size() <= 7 && k.find_first_not_of("0123456789", 4) == std::string::npos &&
@@ -1389,12 +1479,12 @@ int pt_scene_get_info(pt_scene* S, const char* key, int64_t* value) {
         HIP_TRY(hipStreamSynchronize(S->last_stream));
         unsigned long long v = 0;
         const int idx = std::stoi(k.substr(4));
-        if (S->ctl.p && idx < 8) {                  // schedule diagnostics: summed over the counter slots
+        if (S->cur().ctl.p && idx < 8) {                  // schedule diagnostics: summed over the counter slots
             unsigned long long c[kSlotStride];
             int rc = read_slot_sums(S, c);
             if (rc) return rc;
             v = c[4 + idx];
-        } else if (S->ctl.p) {                      // launch timeline / histograms
+        } else if (S->cur().ctl.p) {                      // launch timeline / histograms
             HIP_TRY(hipMemcpy(&v, S->counters() + kTimelineBase + (idx - 8), sizeof v, hipMemcpyDeviceToHost));
         }
         *value = (int64_t)v;
