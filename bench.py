@@ -429,6 +429,11 @@ def main():
         physical = {} if stub else physical_roofline(args.scene, args.traversal, lds_scene, ms_per_step if overlapped else k_ms, passes)
         if physical and overlapped:
             physical["physical_time_base"] = "ms_per_step (launches of consecutive frames overlap: frames_in_flight)"
+        if overlapped:
+            # launches per frame interval: ~2 when two frames share every CU.  `achieved` x this = algorithmic bytes per second of
+            # the kernel as a whole (all resident launches together)
+            physical["launch_overlap"] = round(k_ms / ms_per_step, 3)
+            physical["achieved_all_resident_launches"] = round(achieved * k_ms / ms_per_step, 1)
         work_done_frac = None
         if work and "callers_tree_inner_visits_per_segment" in work:
             # "work avoided is not bandwidth achieved" (SURVEY §8d): the algorithmic figure with the inner visits this run really

@@ -263,7 +263,12 @@ int pt_bvh_build_sweep_device(const pt_scene_desc* desc, pt_bvh_node* out_nodes,
  *   "timing_frames" render calls whose HIP events are kept for pt_get_frame_times (1 .. 4096, default 1)
  *   "frames_in_flight" 1 .. 4 (default 2): sets of per-frame scratch memory (per-sample buffer, work and statistics counters)
  *                   the handle rotates through; with more than one, consecutive render calls overlap as described at
- *                   pt_render_async (frames that need several sample passes run on the caller's stream as with 1).
+ *                   pt_render_async (frames that need several sample passes, and frames that find the GPU idle, run on the
+ *                   caller's stream as with 1).  A frame that overlaps leaves its successor room on every CU: all but one of
+ *                   the resident blocks with 2 slots (never slower than 1 slot, whatever the caller's submission pattern),
+ *                   half of them with 3 or 4 (the fastest for an unbroken stream of frames — bunny 4.41 ms per frame against
+ *                   4.52 with 2 and 4.91 with 1 — but a burst that ends leaves its last frame on half a chip);
+ *                   an explicit "blocks_per_cu" is used as given.
  *                   kernel_ms of a frame that overlapped with its neighbours includes the time its blocks waited for theirs.
  *   "scratch_bytes" cap of the per-sample scratch buffer (0 = 8 GiB); larger jobs run in sample passes
  *   "stats"         1 = also count node visits / leaf tests (pt_counters), schedule diagnostics ("diag0".."diag7") and the

@@ -10,40 +10,37 @@
 
 namespace pth {
 
-// compute_normals.cpp:4-10.  NB the (pi - 2) * asin(...) branch is the reference's
-// behaviour; kept so that shading normals of OBJ meshes without `vn` agree.
-static inline float unit_angle(f3 u, f3 v) {
-    if (dot(u, v) < 0) return (kPi - 2) * asinf(float(0.5) * length(v + u));
-    return 2 * asinf(float(0.5) * length(v - u));
+// Angle between two unit vectors as compute_normals.cpp:4-10 evaluates it, bit for bit: the chord form 2 asin(|b - a| / 2)
+// for acute angles and — the reference's own slip, kept on purpose — (pi - 2) asin(|b + a| / 2) where
+// pi - 2 asin(...) was meant.  Shading normals of OBJ meshes without `vn` lines depend on it.
+static inline float corner_weight(f3 a, f3 b) {
+    const bool obtuse = dot(a, b) < 0;
+    const float half_chord = float(0.5) * length(obtuse ? b + a : b - a);
+    return obtuse ? (kPi - 2) * asinf(half_chord) : 2 * asinf(half_chord);
 }
 
-// compute_normals.cpp:13-51 (Nelson Max angle-weighted vertex normals)
+// Vertex normals weighted by the corner angles of the faces around each vertex (compute_normals.cpp:13-51), same operation
+// order as the reference: faces in index order, corners 0, 1, 2 of a face, unit face normal from corner 0's edges.
 std::vector<f3> compute_normals(const std::vector<f3>& vertices, const std::vector<i3>& indices) {
-    std::vector<f3> normals(vertices.size(), f3{0, 0, 0});
-    for (const i3& index : indices) {
-        const f3& v0 = vertices[index.x];
-        const f3& v1 = vertices[index.y];
-        const f3& v2 = vertices[index.z];
-        f3 side1 = v1 - v0, side2 = v2 - v0;
-        f3 n = cross(side1, side2);
-        float l = length(n);
-        if (l != 0) {
-            n = n / l;
-            float angle0 = unit_angle(normalize(side1), normalize(side2));
-            normals[index.x] = normals[index.x] + n * angle0;
-            side1 = v2 - v1; side2 = v0 - v1;
-            float angle1 = unit_angle(normalize(side1), normalize(side2));
-            normals[index.y] = normals[index.y] + n * angle1;
-            side1 = v0 - v2; side2 = v1 - v2;
-            float angle2 = unit_angle(normalize(side1), normalize(side2));
-            normals[index.z] = normals[index.z] + n * angle2;
+    std::vector<f3> sum(vertices.size(), f3{0, 0, 0});
+    for (const i3& tri : indices) {
+        const int at[3] = {tri.x, tri.y, tri.z};
+        const f3 p[3] = {vertices[at[0]], vertices[at[1]], vertices[at[2]]};
+        f3 face = cross(p[1] - p[0], p[2] - p[0]);
+        const float twice_area = length(face);
+        if (twice_area == 0) continue;                   // degenerate face: contributes nothing (a NaN area falls through, as there)
+        face = face / twice_area;
+        for (int c = 0; c < 3; c++) {
+            const f3 to_next = normalize(p[(c + 1) % 3] - p[c]), to_prev = normalize(p[(c + 2) % 3] - p[c]);
+            sum[at[c]] = sum[at[c]] + face * corner_weight(to_next, to_prev);
         }
     }
-    for (f3& n : normals) {
-        float l = length(n);
-        n = (l != 0) ? n / l : f3{0, 0, 0};
+    for (f3& n : sum) {
+        const float len = length(n);
+        if (len != 0) n = n / len;
+        else n = f3{0, 0, 0};
     }
-    return normals;
+    return sum;
 }
 
 namespace {

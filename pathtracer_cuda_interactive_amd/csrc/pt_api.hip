@@ -1120,6 +1120,14 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     // worth having: bunny +0.6 %, buddha stand-in -1.1 %, dragon stand-in -7.6 % against 5 blocks of 31 KB
     // (profiles/r02_tune_round41_lds_budget.log, r02_tune_round42_blocks.log).  LDS-resident scenes take every block they can get.
     int bpc = S->opt_blocks_per_cu > 0 ? (int)S->opt_blocks_per_cu : (!lds_scene ? std::min(occ, 6) : occ);
+    // Single-pass frames of a handle with more than one slot run on the slot's stream while an earlier frame is on the GPU
+    // (pt_scene::FrameSlot).  Such a frame does not take every resident slot of the chip: the waves of a launch run dry
+    // together, and while its blocks sit on their last few paths a successor that may only ENTER as they leave starts late.
+    // With three slots a frame takes half of each CU — two frames are resident side by side, half a frame apart, the third
+    // enters where the first leaves — with two slots all but one block per CU (cbox 2.55 ms per frame with full grids,
+    // 2.50 with 5 + 1 of 6, 2.49 with 3 + 3 and three slots; bunny 4.64 / 4.53 / 4.39; profiles/r03_frames_in_flight.log).
+    const bool own_stream = in_flight > 1 && n_pass == 1 && prev_busy;
+    if (own_stream && S->opt_blocks_per_cu <= 0) bpc = std::max(1, in_flight >= 3 ? bpc / 2 : bpc - 1);
     S->info_kernel = use_q ? 3 : S->opt_kernel == 1 ? 1 : 2;
     S->info_occupancy = occ;
     S->info_blocks_per_cu = bpc;
@@ -1136,8 +1144,6 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     }
     select_tree(S, which, which == 1);
     float* accum = mode == 2 ? out_dev : S->accum.p;
-    // Single-pass frames of a handle with more than one slot run on the slot's stream (pt_scene::FrameSlot)
-    const bool own_stream = in_flight > 1 && n_pass == 1 && prev_busy;
     hipStream_t tstream = stream;
     if (own_stream) {
         if (!slot.stream) {

@@ -150,3 +150,39 @@ def test_frame_times_of_overlapped_frames(cbox):
         assert len(k_ms) == 6 and all(t > 0 for t in k_ms) and all(t > 0 for t in r_ms)
     finally:
         ds.set_option("timing_frames", 1)
+
+
+def test_grid_of_a_frame_that_overlaps_with_its_predecessor(cbox):
+    """A frame launched while the previous one is still on the GPU leaves room for its successor: all but one block per CU with
+    two slots, half of them with three; a frame that finds the GPU idle, or a caller's own blocks_per_cu, takes what it took before."""
+    import torch
+    hs, _, ds = cbox
+    p = hs.render_params(640, 480, 16, seed=9)
+    out = torch.zeros(480, 640, 3, dtype=torch.float32, device="cuda")
+    ds.set_option("frames_in_flight", 1)
+    ds.render_into(p, out.data_ptr())
+    torch.cuda.synchronize()
+    full = ds.info("blocks_per_cu")
+    assert full == ds.info("occupancy") and full >= 2
+    want = bits(out).copy()
+    try:
+        for depth, expect in ((2, full - 1), (3, max(1, full // 2))):
+            ds.set_option("frames_in_flight", depth)
+            torch.cuda.synchronize()
+            ds.render_into(p, out.data_ptr())
+            assert ds.info("blocks_per_cu") == full                 # nothing on the GPU: the whole chip
+            for _ in range(3):
+                ds.render_into(p, out.data_ptr())
+            assert ds.info("blocks_per_cu") == expect
+            torch.cuda.synchronize()
+            assert (bits(out) == want).all()
+            ds.set_option("blocks_per_cu", full)
+            for _ in range(3):
+                ds.render_into(p, out.data_ptr())
+            assert ds.info("blocks_per_cu") == full
+            ds.set_option("blocks_per_cu", 0)
+            torch.cuda.synchronize()
+            assert (bits(out) == want).all()
+    finally:
+        ds.set_option("blocks_per_cu", 0)
+        ds.set_option("frames_in_flight", 2)

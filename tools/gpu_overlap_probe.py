@@ -36,6 +36,9 @@ def main():
         caller = torch.cuda.Stream().cuda_stream if handles == 0 else None
         outs = [torch.empty(h, w, 3, dtype=torch.float32, device="cuda") for _ in range(2)]
         want = one.render(params).view(np.uint32).reshape(h, w, 3)
+        burst = int(os.environ.get("PT_PROBE_BURST", "0"))
+        if burst:
+            print(f"bursts of {burst} frames, a device synchronise after each", flush=True)
         for depth in (1, 2, 3, 4, 2, 1):
             one.set_option("frames_in_flight", depth)
             ts = []
@@ -44,6 +47,8 @@ def main():
                 t0 = time.perf_counter()
                 for i in range(frames):
                     one.render_into(params, outs[i % 2].data_ptr(), stream=caller)
+                    if burst and (i + 1) % burst == 0:
+                        torch.cuda.synchronize()                 # a caller that submits `burst` frames and waits for them
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) / frames * 1e3)
             same = all(bool((o.cpu().numpy().view(np.uint32) == want).all()) for o in outs)
