@@ -14,6 +14,10 @@ BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-work-frames 
 echo "== kernel trace" | tee $OUT/log.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE > $OUT/bench_trace.out 2>> $OUT/log.txt || exit 1
 grep '^{' $OUT/bench_trace.out | tail -1 > $OUT/bench_line.json
+if [ -n "$PT_PROFILE_TRACE_ONLY" ]; then      # only the per-kernel durations (the counter passes of an unchanged kernel need no rerun)
+  find $OUT/trace -type f ! -name "*_kernel_stats.csv" -delete
+  exit 0
+fi
 # Every pass under its own timeout (a pass that asks for more counters than a block has slots aborts and then hangs).
 # TCP_TOTAL_CACHE_ACCESSES = L1 tag lookups (one per active lane and 16-B load of a divergent access): the rate that binds scenes in
 # global memory.  TCC: 4 slots (FETCH_SIZE takes 3, WRITE_SIZE 2), SQ: 8, GRBM: 2.  TCC_EA0_RDREQ_{32B,64B,128B} split the L2's fabric-side
