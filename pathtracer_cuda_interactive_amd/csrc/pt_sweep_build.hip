@@ -26,6 +26,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan_by_key.hpp>
 #include <rocprim/iterator/reverse_iterator.hpp>
+#include <hipcub/block/block_scan.hpp>
 
 #include <chrono>
 #include <cstring>
@@ -141,6 +142,207 @@ __global__ void cand3_kernel(const SB3 pre, const SB3 suf, const uint32_t* __res
     }
     best[i] = c;
 }
+// ---- the box scans and the cut search of a level in three launches ------------------------------------------------------------
+// The six segmented scans above (rocPRIM, one launch or two each, 52 B of traffic per element and scan) and cand3_kernel read and
+// write 480 B per element and level; the cut search needs none of the scanned boxes in memory — only, per position, the best of
+// three costs.  Tiles of 1,024 positions: (A) every tile's aggregate per order and direction, (B) the carries into the tiles (a
+// segmented scan over the aggregates, six small blocks), (C) per tile and order both scans again with their carries, the suffix
+// boxes through LDS, the prefix boxes in registers, and the best cut after every position straight out: 168 B per element.
+// The operator is the segmented form of MergeKeepFirst — (earlier, later) in scan order, so the bits are the sequential sweep's.
+constexpr int kScanT = 256, kScanI = 4, kTile = kScanT * kScanI;
+struct FSB {
+    SB v;
+    uint32_t head;              // 1: a segment starts here (in scan direction); 2: nothing (identity)
+};
+struct SegMerge {
+    __device__ FSB operator()(const FSB& a, const FSB& b) const {
+        if (b.head == 2u) return a;
+        if (b.head == 1u || a.head == 2u) return b;
+        FSB r;
+        r.v = MergeKeepFirst()(a.v, b.v);
+        r.head = a.head;
+        return r;
+    }
+};
+__device__ __forceinline__ FSB fsb_none() {
+    FSB r;
+    for (int k = 0; k < 3; k++) { r.v.lo[k] = 0.0f; r.v.hi[k] = 0.0f; }
+    r.head = 2u;
+    return r;
+}
+// the same for the cut candidates: a node's best cut = the segmented minimum over its positions.  Tiles write the running minimum
+// at every node's LAST position and their aggregate; a node that began in an earlier tile adds the carry into its last tile
+// (apply_kernel).  This replaces a scan-by-key over all positions (rocPRIM: 107 us a level for 1.15 M) and the 16-B-per-position
+// array it read.
+struct FC {
+    Cand c;
+    uint32_t head;
+};
+struct SegMin {
+    __device__ FC operator()(const FC& a, const FC& b) const {
+        if (b.head == 2u) return a;
+        if (b.head == 1u || a.head == 2u) return b;
+        FC r;
+        r.c = CandMin()(a.c, b.c);
+        r.head = a.head;
+        return r;
+    }
+};
+__device__ __forceinline__ FC fc_none() { return FC{cand_none(), 2u}; }
+__device__ __forceinline__ void set_none(FSB& x) { x = fsb_none(); }
+__device__ __forceinline__ void set_none(FC& x) { x = fc_none(); }
+// Exclusive SegMin scan of one FC per thread through LDS (sh: 2 x NT entries); `total` = the fold of all of them.
+// (hipcub::BlockScan<FC, ...> sends this compiler's MachineCopyPropagation pass into a segmentation fault: ROCm 7.2.0, clang 22.)
+template <int NT>
+__device__ __forceinline__ FC block_exclusive_min(FC local, FC* sh, FC& total) {
+    const int t = threadIdx.x;
+    int cur = 0;
+    sh[t] = local;
+    __syncthreads();
+    for (int d = 1; d < NT; d <<= 1) {
+        FC v = sh[cur * NT + t];
+        if (t >= d) v = SegMin()(sh[cur * NT + t - d], v);
+        sh[(cur ^ 1) * NT + t] = v;
+        __syncthreads();
+        cur ^= 1;
+    }
+    total = sh[cur * NT + NT - 1];
+    return t ? sh[cur * NT + t - 1] : fc_none();
+}
+// position of item j of thread t: forward tiles run left to right, reverse tiles right to left
+__device__ __forceinline__ int tile_pos(int base, int t, int j, bool rev) {
+    const int r = t * kScanI + j;
+    return rev ? base + kTile - 1 - r : base + r;
+}
+__device__ __forceinline__ FSB tile_item(const SB* __restrict__ bx, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
+                                         int n, int i, bool rev) {
+    if (i >= n) return fsb_none();
+    FSB r;
+    r.v = bx[i];
+    r.head = rev ? (seg_e[i] == (uint32_t)i + 1u ? 1u : 0u) : (seg_b[i] == (uint32_t)i ? 1u : 0u);
+    return r;
+}
+// (A) agg[(order * 2 + direction) * tiles + tile]
+__global__ __launch_bounds__(kScanT) void tile_agg_kernel(const SB3 bx, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
+                                                          int n, int tiles, FSB* __restrict__ agg) {
+    using Scan = hipcub::BlockScan<FSB, kScanT>;
+    __shared__ typename Scan::TempStorage tmp;
+    const int tile = blockIdx.x, a = blockIdx.y, base = tile * kTile;
+    for (int dir = 0; dir < 2; dir++) {
+        FSB local = fsb_none();
+        for (int j = 0; j < kScanI; j++)
+            local = SegMerge()(local, tile_item(bx.a[a], seg_b, seg_e, n, tile_pos(base, threadIdx.x, j, dir == 1), dir == 1));
+        FSB scanned, total;
+        Scan(tmp).InclusiveScan(local, scanned, SegMerge(), total);
+        if (threadIdx.x == 0) agg[(size_t)(a * 2 + dir) * tiles + tile] = total;
+        __syncthreads();
+    }
+}
+// (B) carry into tile t = everything before it in scan direction, folded: one block per order and direction
+template <class E, class Op>
+__global__ __launch_bounds__(1024) void tile_carry_kernel(const E* __restrict__ agg, int tiles, E* __restrict__ carry) {
+    using Scan = hipcub::BlockScan<E, 1024>;
+    __shared__ typename Scan::TempStorage tmp;
+    const bool rev = (blockIdx.x & 1) != 0;
+    const E* in = agg + (size_t)blockIdx.x * tiles;
+    E* out = carry + (size_t)blockIdx.x * tiles;
+    const int per = (tiles + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * per, tiles), hi = min(lo + per, tiles);
+    E none;
+    set_none(none);
+    E local = none;
+    for (int p = lo; p < hi; p++) local = Op()(local, in[rev ? tiles - 1 - p : p]);
+    E run;
+    Scan(tmp).ExclusiveScan(local, run, none, Op());
+    for (int p = lo; p < hi; p++) {
+        const int t = rev ? tiles - 1 - p : p;
+        out[t] = run;
+        run = Op()(run, in[t]);
+    }
+}
+// the carries of the cut candidates: one block, left to right
+constexpr int kCarryT = 256;
+__global__ __launch_bounds__(kCarryT) void cand_carry_kernel(const FC* __restrict__ in, int tiles, FC* __restrict__ out) {
+    __shared__ FC sh[2 * kCarryT];
+    const int per = (tiles + kCarryT - 1) / kCarryT;
+    const int lo = min((int)threadIdx.x * per, tiles), hi = min(lo + per, tiles);
+    FC local = fc_none();
+    for (int p = lo; p < hi; p++) local = SegMin()(local, in[p]);
+    FC total;
+    FC run = block_exclusive_min<kCarryT>(local, sh, total);
+    for (int p = lo; p < hi; p++) {
+        out[p] = run;
+        run = SegMin()(run, in[p]);
+    }
+}
+// (C) best cut after every position (cand3_kernel's arithmetic, operand for operand) and the node's box at its first position
+__global__ __launch_bounds__(kScanT) void tile_cand_kernel(const SB3 bx, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
+                                                           int n, int tiles, const FSB* __restrict__ carry, Cand* __restrict__ best_at_end,
+                                                           FC* __restrict__ best_agg, SB* __restrict__ whole) {
+    using Scan = hipcub::BlockScan<FSB, kScanT>;
+    __shared__ typename Scan::TempStorage tmp;
+    __shared__ SB suf_sh[kTile + 1];
+    static_assert(sizeof(SB) * (kTile + 1) >= sizeof(FC) * 2 * kScanT, "the candidate scan reuses the suffix boxes' LDS");
+    const int tile = blockIdx.x, base = tile * kTile, t = threadIdx.x;
+    uint32_t sb[kScanI], se[kScanI];
+    Cand c[kScanI];
+    for (int j = 0; j < kScanI; j++) {
+        const int i = tile_pos(base, t, j, false);
+        sb[j] = i < n ? seg_b[i] : 0u;
+        se[j] = i < n ? seg_e[i] : 0u;
+        c[j] = cand_none();
+    }
+    FSB it[kScanI];
+    for (int a = 0; a < 3; a++) {
+        // suffix boxes: right to left, into LDS by position; suf_sh[kTile] = the run that starts right of the tile
+        for (int j = 0; j < kScanI; j++) it[j] = tile_item(bx.a[a], seg_b, seg_e, n, tile_pos(base, t, j, true), true);
+        Scan(tmp).InclusiveScan(it, it, SegMerge());
+        const FSB cr = carry[(size_t)(a * 2 + 1) * tiles + tile];
+        for (int j = 0; j < kScanI; j++) {
+            const int i = tile_pos(base, t, j, true);
+            if (i < n) suf_sh[i - base] = it[j].head ? it[j].v : MergeKeepFirst()(cr.v, it[j].v);   // no segment end in [i, tile end): it runs on
+        }
+        if (t == 0) suf_sh[kTile] = cr.v;
+        __syncthreads();
+        // prefix boxes: left to right, in registers
+        for (int j = 0; j < kScanI; j++) it[j] = tile_item(bx.a[a], seg_b, seg_e, n, tile_pos(base, t, j, false), false);
+        Scan(tmp).InclusiveScan(it, it, SegMerge());
+        const FSB cf = carry[(size_t)(a * 2 + 0) * tiles + tile];
+        for (int j = 0; j < kScanI; j++) {
+            const int i = tile_pos(base, t, j, false);
+            if (i >= n) continue;
+            const uint32_t b = sb[j], e = se[j];
+            if (a == 0 && (uint32_t)i == b) whole[b] = clamp_like_host(suf_sh[i - base]);
+            if ((uint32_t)i + 1 < e) {
+                const SB pre = it[j].head ? it[j].v : MergeKeepFirst()(cf.v, it[j].v);
+                const int k = i - (int)b + 1, m = (int)(e - b);
+                const int off = 2 * k > m ? 2 * k - m : m - 2 * k;
+                Cand x;
+                x.cost = area_like_host(clamp_like_host(pre)) * k + area_like_host(clamp_like_host(suf_sh[i + 1 - base])) * (m - k);
+                x.off = off;
+                x.ak = (a << 28) | k;
+                c[j] = a == 0 ? x : CandMin()(c[j], x);
+            }
+        }
+        __syncthreads();
+    }
+    // the running minimum of every node up to each position; kept where a node ends, and the tile's aggregate for the carries
+    FC fc[kScanI];
+    for (int j = 0; j < kScanI; j++) {
+        const int i = tile_pos(base, t, j, false);
+        fc[j] = i < n ? FC{c[j], (uint32_t)i == sb[j] ? 1u : 0u} : fc_none();
+    }
+    FC local = fc_none();
+    for (int j = 0; j < kScanI; j++) local = SegMin()(local, fc[j]);
+    FC total;
+    FC run = block_exclusive_min<kScanT>(local, reinterpret_cast<FC*>(suf_sh), total);     // (the axis loop ended with a barrier)
+    for (int j = 0; j < kScanI; j++) {
+        const int i = tile_pos(base, t, j, false);
+        run = SegMin()(run, fc[j]);
+        if (i < n && (uint32_t)i + 1 == se[j]) best_at_end[i] = run.c;
+    }
+    if (t == 0) best_agg[tile] = total;
+}
 __global__ void mark_left3_kernel(const uint32_t* __restrict__ seg_b, const int32_t* __restrict__ split, const I3* __restrict__ idx, int n,
                                   unsigned char* __restrict__ left) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,7 +387,7 @@ struct BuildCtl {
 
 // One thread per position; the one that starts a node emits it and splits it.  best_scan = inclusive segmented min-scan of the
 // cut candidates: a node's best cut stands at its last position.  The level's control words are summed per block first.
-__global__ void apply_kernel(const Cand* __restrict__ best_scan, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
+__global__ void apply_kernel(const Cand* __restrict__ best_scan, const FC* __restrict__ best_carry, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
                              const SB* __restrict__ whole, const I3* __restrict__ idx3, const SB* __restrict__ bx0, int n,
                              int32_t* __restrict__ slot, int32_t* __restrict__ split, pt_bvh_node* __restrict__ out, int depth,
                              int guard_depth, BuildCtl* __restrict__ ctl) {
@@ -211,7 +413,11 @@ __global__ void apply_kernel(const Cand* __restrict__ best_scan, const uint32_t*
             sh_deep = 1u;
             split[b] = 0;
         } else {
-            const Cand c = best_scan[e - 1];
+            Cand c = best_scan[e - 1];
+            if (best_carry) {                           // tiled search: best_scan[e - 1] covers the node's part of its last tile
+                const uint32_t last_tile = (e - 1) / (uint32_t)kTile;
+                if (b < last_tile * (uint32_t)kTile) c = CandMin()(best_carry[last_tile].c, c);
+            }
             const int axis = c.ak >> 28, k = c.ak & 0x0fffffff;
             pt_bvh_node nd;
             for (int q = 0; q < 3; q++) { nd.bmin[q] = whole[b].lo[q]; nd.bmax[q] = whole[b].hi[q]; }
@@ -240,7 +446,10 @@ __global__ void apply_kernel(const Cand* __restrict__ best_scan, const uint32_t*
 // host builder's own sequential steps (pt_tree_sweep.h: process / run_subtree — the same sweeps, the same comparisons in the same
 // order, hence the same bytes) on a private copy of the node's three orders.  The last six to eight levels of a build — as
 // many launches-times-whole-array passes as all the levels above them — become one launch.
-constexpr int kSmall = 32;      // 16 costs a level more, 64 makes the one-thread subtrees the long pole (buddha stand-in: 30.8 ms at 32, 32.1 at 64)
+#ifndef PT_SWEEP_SMALL
+#define PT_SWEEP_SMALL 16
+#endif
+constexpr int kSmall = PT_SWEEP_SMALL;      // 64 makes the one-thread subtrees the long pole; 32 was the optimum while a level cost ~0.9 ms, with the tiled scans (~0.55 ms a level) it is 16: builder 12.8 -> 12.0 ms for 1.15 M triangles
 __device__ __forceinline__ void merge_host(SB& a, const SB& b) {         // pts::sbox_merge
     for (int k = 0; k < 3; k++) {
         a.lo[k] = b.lo[k] < a.lo[k] ? b.lo[k] : a.lo[k];
@@ -404,12 +613,21 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     const size_t t_bytes = std::max(std::max(std::max(t_sort, t_scan_box), std::max(t_scan_box_r, t_scan_u)), t_reduce);
     const size_t nn = (size_t)n;
     size_t o_bx[3], o_bxa[3], o_pre[3], o_suf[3];
-    for (int a = 0; a < 3; a++) { o_bx[a] = arena.reserve(nn * sizeof(SB)); o_bxa[a] = arena.reserve(nn * sizeof(SB)); o_pre[a] = arena.reserve(nn * sizeof(SB)); o_suf[a] = arena.reserve(nn * sizeof(SB)); }
+    // PT_SWEEP_SCANS=rocprim: the box scans as six rocPRIM scans-by-key + cand3_kernel (A/B timing; same tree)
+    const char* scans_env = std::getenv("PT_SWEEP_SCANS");
+    const bool tiled = !(scans_env && std::string(scans_env) == "rocprim");
+    const int tiles = (n + kTile - 1) / kTile;
+    for (int a = 0; a < 3; a++) {
+        o_bx[a] = arena.reserve(nn * sizeof(SB)); o_bxa[a] = arena.reserve(nn * sizeof(SB));
+        o_pre[a] = tiled ? 0 : arena.reserve(nn * sizeof(SB)); o_suf[a] = tiled ? 0 : arena.reserve(nn * sizeof(SB));
+    }
+    const size_t o_agg = arena.reserve((size_t)tiles * 6 * sizeof(FSB)), o_carry = arena.reserve((size_t)tiles * 6 * sizeof(FSB));
+    const size_t o_aggc = arena.reserve((size_t)tiles * sizeof(FC)), o_carryc = arena.reserve((size_t)tiles * sizeof(FC));
     const size_t o_idx = arena.reserve(nn * sizeof(I3)), o_idxa = arena.reserve(nn * sizeof(I3)), o_whole = arena.reserve(nn * sizeof(SB));
     const size_t o_slot = arena.reserve(nn * 4), o_split = arena.reserve(nn * 4), o_keys = arena.reserve(nn * 8), o_keysa = arena.reserve(nn * 8);
     const size_t o_sb = arena.reserve(nn * 4), o_se = arena.reserve(nn * 4), o_sba = arena.reserve(nn * 4), o_sea = arena.reserve(nn * 4);
     const size_t o_flags = arena.reserve(nn * sizeof(U3)), o_rank = arena.reserve(nn * sizeof(U3));
-    const size_t o_best = arena.reserve(nn * sizeof(Cand)), o_bests = arena.reserve(nn * sizeof(Cand)), o_left = arena.reserve(nn);
+    const size_t o_best = tiled ? 0 : arena.reserve(nn * sizeof(Cand)), o_bests = arena.reserve(nn * sizeof(Cand)), o_left = arena.reserve(nn);
     const size_t o_ctl = arena.reserve(sizeof(BuildCtl)), o_temp = arena.reserve(t_bytes);
     HIPS(hipMalloc(reinterpret_cast<void**>(&arena.base), arena.used));
     for (int a = 0; a < 3; a++) {
@@ -426,6 +644,10 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     best.p = reinterpret_cast<Cand*>(arena.base + o_best); best_seg.p = reinterpret_cast<Cand*>(arena.base + o_bests);
     left.p = arena.base + o_left; temp.p = arena.base + o_temp;
     ctl.p = reinterpret_cast<BuildCtl*>(arena.base + o_ctl);
+    FSB* const agg = reinterpret_cast<FSB*>(arena.base + o_agg);
+    FSB* const carry = reinterpret_cast<FSB*>(arena.base + o_carry);
+    FC* const agg_c = reinterpret_cast<FC*>(arena.base + o_aggc);
+    FC* const carry_c = reinterpret_cast<FC*>(arena.base + o_carryc);
 
     hipEvent_t ev0, ev1;
     HIPS(hipEventCreate(&ev0));
@@ -452,20 +674,27 @@ int pts::sweep_build_on_device(const float* leaf_boxes_dev, int n, pt_bvh_node* 
     for (;; depth++) {
         if (depth > guard_depth + 2) return pt_fail(PT_ERR_UNSUPPORTED, "sweep_build_device: deeper than the host builder's guard");
         size_t tb = t_bytes;
-        for (int a = 0; a < 3; a++) {
+        if (tiled) {
+            hipLaunchKernelGGL(tile_agg_kernel, dim3(tiles, 3), dim3(kScanT), 0, nullptr, cur_bx, cur_b, cur_e, n, tiles, agg);
+            hipLaunchKernelGGL((tile_carry_kernel<FSB, SegMerge>), dim3(6), dim3(1024), 0, nullptr, agg, tiles, carry);
+            hipLaunchKernelGGL(tile_cand_kernel, dim3(tiles), dim3(kScanT), 0, nullptr, cur_bx, cur_b, cur_e, n, tiles, carry, best_seg.p, agg_c, whole.p);
+            hipLaunchKernelGGL(cand_carry_kernel, dim3(1), dim3(kCarryT), 0, nullptr, agg_c, tiles, carry_c);
+        } else {
+            for (int a = 0; a < 3; a++) {
+                tb = t_bytes;
+                HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, cur_bx.a[a], pre.a[a], (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
+                auto kr = rocprim::make_reverse_iterator(cur_b + n);
+                auto vr = rocprim::make_reverse_iterator(cur_bx.a[a] + n);
+                auto orr = rocprim::make_reverse_iterator(suf.a[a] + n);
+                tb = t_bytes;
+                HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, kr, vr, orr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
+            }
+            hipLaunchKernelGGL(cand3_kernel, dim3(G), dim3(T), 0, nullptr, pre, suf, cur_b, cur_e, n, best.p, whole.p);
             tb = t_bytes;
-            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, cur_bx.a[a], pre.a[a], (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
-            auto kr = rocprim::make_reverse_iterator(cur_b + n);
-            auto vr = rocprim::make_reverse_iterator(cur_bx.a[a] + n);
-            auto orr = rocprim::make_reverse_iterator(suf.a[a] + n);
-            tb = t_bytes;
-            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, kr, vr, orr, (size_t)n, MergeKeepFirst(), rocprim::equal_to<uint32_t>(), nullptr));
+            HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, best.p, best_seg.p, (size_t)n, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
         }
-        hipLaunchKernelGGL(cand3_kernel, dim3(G), dim3(T), 0, nullptr, pre, suf, cur_b, cur_e, n, best.p, whole.p);
-        tb = t_bytes;
-        HIPS(rocprim::inclusive_scan_by_key(temp.p, tb, cur_b, best.p, best_seg.p, (size_t)n, CandMin(), rocprim::equal_to<uint32_t>(), nullptr));
         HIPS(hipMemsetAsync(ctl.p, 0, sizeof(unsigned int) * 3, nullptr));           // active, too_deep, max_child (max_depth stays)
-        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, best_seg.p, cur_b, cur_e, whole.p, cur_idx, cur_bx.a[0], n,
+        hipLaunchKernelGGL(apply_kernel, dim3(G), dim3(T), 0, nullptr, best_seg.p, tiled ? carry_c : nullptr, cur_b, cur_e, whole.p, cur_idx, cur_bx.a[0], n,
                            slot.p, split.p, nodes.p, depth, guard_depth, ctl.p);
         HIPS(hipGetLastError());
         HIPS(hipMemcpy(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost));
