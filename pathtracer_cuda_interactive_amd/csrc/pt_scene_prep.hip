@@ -169,61 +169,79 @@ __device__ __forceinline__ double relay_area(const pt_bvh_node& b) {
     const double x = (double)b.bmax[0] - b.bmin[0], y = (double)b.bmax[1] - b.bmin[1], z = (double)b.bmax[2] - b.bmin[2];
     return 2.0 * (x * y + y * z + z * x);
 }
-// The `want` inner nodes with the largest boxes, parents before children (pt_api.hip: convert_tree has the argument): one
-// thread, a binary max-heap of (area, -pre-order position) in LDS.  top[j] = pool index of the j-th pick.
+// The `want` inner nodes with the largest boxes, parents before children (pt_api.hip: convert_tree has the argument): the host
+// pops a max-heap of (area, -pre-order position) — a total order, so the sequence of picks is simply "the largest entry of the
+// frontier, `want` times".  One wave: the frontier sits unsorted in LDS, every pick is a 64-lane argmax over it (at most `want` + 1
+// entries), lanes 0 and 1 fetch the picked node's two children in one round trip (an entry carries its children's indices), the
+// children that are inner nodes take the freed place and the end of the list.  top[j] = pool index of the j-th pick.
+// (First version: one thread and a binary heap in LDS — 2.7 us a pick, 1.4 ms per tree; the heap's dependent LDS steps cost more
+// than its global loads.)
 constexpr int kHeapCap = 2048;
-__global__ void relay_top_kernel(const pt_bvh_node* __restrict__ pool, int root, const int32_t* __restrict__ pre, int want,
-                                 int32_t* __restrict__ top, int32_t* __restrict__ top_pre, int32_t* __restrict__ n_top) {
-    __shared__ double h_area[kHeapCap];
-    __shared__ int32_t h_neg[kHeapCap], h_node[kHeapCap];
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int size = 0, picked = 0;
-    auto less = [&](int a, int b) {            // heap order: a below b
-        return h_area[a] < h_area[b] || (h_area[a] == h_area[b] && h_neg[a] < h_neg[b]);
-    };
-    auto push = [&](double ar, int32_t neg, int32_t node) {
-        if (size >= kHeapCap) return;
-        int i = size++;
-        h_area[i] = ar; h_neg[i] = neg; h_node[i] = node;
-        while (i > 0) {
-            const int p = (i - 1) / 2;
-            if (!less(p, i)) break;
-            const double ta = h_area[p]; h_area[p] = h_area[i]; h_area[i] = ta;
-            const int32_t tn = h_neg[p]; h_neg[p] = h_neg[i]; h_neg[i] = tn;
-            const int32_t tk = h_node[p]; h_node[p] = h_node[i]; h_node[i] = tk;
-            i = p;
+__global__ __launch_bounds__(64) void relay_top_kernel(const pt_bvh_node* __restrict__ pool, int root, const int32_t* __restrict__ pre, int want,
+                                                       int32_t* __restrict__ top, int32_t* __restrict__ top_pre, int32_t* __restrict__ n_top) {
+    __shared__ double f_area[kHeapCap];
+    __shared__ int32_t f_neg[kHeapCap], f_node[kHeapCap], f_left[kHeapCap], f_right[kHeapCap];
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    int size = 0, picked = 0;                            // wave-uniform
+    if (want > 0) {
+        if (lane == 0) {
+            const pt_bvh_node nd = pool[root];
+            f_area[0] = __builtin_huge_val(); f_neg[0] = 0; f_node[0] = root; f_left[0] = nd.left; f_right[0] = nd.right;
         }
-    };
-    if (want > 0) push(__builtin_huge_val(), 0, root);
-    while (size > 0 && picked < want) {
-        const int32_t k = h_node[0];
-        const int32_t h_neg_popped = h_neg[0];
-        size--;
-        if (size > 0) {
-            h_area[0] = h_area[size]; h_neg[0] = h_neg[size]; h_node[0] = h_node[size];
-            int i = 0;
-            for (;;) {
-                int m = i;
-                const int l = 2 * i + 1, r = 2 * i + 2;
-                if (l < size && less(m, l)) m = l;
-                if (r < size && less(m, r)) m = r;
-                if (m == i) break;
-                const double ta = h_area[m]; h_area[m] = h_area[i]; h_area[i] = ta;
-                const int32_t tn = h_neg[m]; h_neg[m] = h_neg[i]; h_neg[i] = tn;
-                const int32_t tk = h_node[m]; h_node[m] = h_node[i]; h_node[i] = tk;
-                i = m;
-            }
-        }
-        top_pre[picked] = -h_neg_popped;
-        top[picked++] = k;
-        // the two children's records and pre-order positions: four independent loads, one wait
-        const pt_bvh_node nd = pool[k];
-        const pt_bvh_node c0 = pool[nd.left], c1 = pool[nd.right];
-        const int32_t p0 = pre[nd.left], p1 = pre[nd.right];
-        if (c0.prim == -1) push(relay_area(c0), -p0, nd.left);
-        if (c1.prim == -1) push(relay_area(c1), -p1, nd.right);
+        size = 1;
     }
-    *n_top = picked;
+    __syncthreads();
+    while (size > 0 && picked < want) {
+        double ba = 0.0;
+        int32_t bn = 0;
+        int bi = -1;
+        for (int k = lane; k < size; k += 64) {
+            const double a = f_area[k];
+            const int32_t g = f_neg[k];
+            if (bi < 0 || a > ba || (a == ba && g > bn)) { ba = a; bn = g; bi = k; }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const double oa = __shfl_xor(ba, off);
+            const int32_t og = __shfl_xor(bn, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi >= 0 && (bi < 0 || oa > ba || (oa == ba && og > bn))) { ba = oa; bn = og; bi = oi; }
+        }
+        const int32_t node = f_node[bi];
+        const int32_t child = lane == 0 ? f_left[bi] : f_right[bi];
+        if (lane == 0) { top_pre[picked] = -bn; top[picked] = node; }
+        picked++;
+        // lanes 0 and 1: the two children's records and pre-order positions
+        bool inner = false;
+        double c_area = 0.0;
+        int32_t c_neg = 0, c_left = 0, c_right = 0;
+        if (lane < 2) {
+            const pt_bvh_node c = pool[child];
+            inner = c.prim == -1;
+            c_area = relay_area(c);
+            c_neg = -pre[child];
+            c_left = c.left; c_right = c.right;
+        }
+        const bool in0 = __shfl((int)inner, 0) != 0, in1 = __shfl((int)inner, 1) != 0;
+        __syncthreads();                                 // every lane has read the frontier
+        const int last = size - 1;
+        if (!in0 && !in1) {
+            if (lane == 0 && bi != last) {               // the pick's place goes to the last entry
+                f_area[bi] = f_area[last]; f_neg[bi] = f_neg[last]; f_node[bi] = f_node[last]; f_left[bi] = f_left[last]; f_right[bi] = f_right[last];
+            }
+            size = last;
+        } else {
+            // the first inner child takes the pick's place, a second one the end of the list (dropped when the list is full,
+            // as the heap version dropped it: `want` is at most kTopNodes = 512 in this library)
+            const int at = lane == 0 ? (in0 ? bi : -1) : lane == 1 ? (in0 ? (size < kHeapCap ? size : -1) : bi) : -1;
+            if (lane < 2 && inner && at >= 0) {
+                f_area[at] = c_area; f_neg[at] = c_neg; f_node[at] = child; f_left[at] = c_left; f_right[at] = c_right;
+            }
+            if (in0 && in1 && size < kHeapCap) size++;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) *n_top = picked;
 }
 // final DNode index: the picks first, in pick order; the rest keep their pre-order among themselves
 __global__ void relay_final_index_kernel(const pt_bvh_node* __restrict__ pool, int num_nodes, const int32_t* __restrict__ pre,
