@@ -94,22 +94,38 @@ def progressive_mode(args, hs, desc, wl):
     spf = args.progressive
     W, H = 640, 480
     ds = DeviceScene(desc)
+    for kv in args.set:
+        k, v = kv.split("=")
+        ds.set_option(k, int(v))
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     p = hs.render_params(W, H, spf)
     p.stream_stride = 1 << 20
 
+    lag = max(0, args.display_lag)
+    shown = [torch.empty_like(acc) for _ in range(lag + 1)]       # what a display would read: a copy of the accumulation buffer per frame
+    done = [torch.cuda.Event() for _ in range(lag + 1)]
+
     def frame(k):
         p.sample_offset = k * spf
         ds.accumulate_into(p, acc.data_ptr(), stream)
-        torch.cuda.synchronize()
+        if lag == 0:
+            torch.cuda.synchronize()                               # one host sync per frame
+            return
+        # a display that runs `lag` frames behind: frame k's image is copied out on the stream, the host waits for frame k - lag's
+        shown[k % (lag + 1)].copy_(acc)
+        done[k % (lag + 1)].record()
+        if k >= lag:
+            done[(k - lag) % (lag + 1)].synchronize()
 
     for k in range(args.warmup):
         frame(k)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     segs = 0
     for k in range(args.steps):
         frame(args.warmup + k)
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     c = ds.counters()
     fps = args.steps / elapsed
@@ -119,7 +135,9 @@ def progressive_mode(args, hs, desc, wl):
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": round(fps / (sum(ref) / 2), 1) if ref and spf == 2 else None, "dtype": "f32",
            "data": "synthetic: scene fixture, PCG seed 1984",
-           "config": {"workload": f"{wl['label'].split(' (')[0].rsplit(' ', 2)[0]} 640x480, {spf} spp per frame, accumulate + host sync per frame",
+           "config": {"workload": f"{wl['label'].split(' (')[0].rsplit(' ', 2)[0]} 640x480, {spf} spp per frame, accumulate + "
+                                  + ("host sync per frame" if lag == 0 else f"copy-out per frame, the host waits for the frame {lag} behind"),
+                      "display_lag": lag, "frames_in_flight": int(ds.info("frames_in_flight")),
                       "kernel_ms_last_frame": round(c.kernel_ms, 4), "segments_last_frame": int(c.segments),
                       "reference_fps_rtx3080_with_ui": list(ref) if ref else None,
                       "note": "reference FPS includes its CPU tonemap + OpenGL upload per frame; this number has no display"}}
@@ -274,6 +292,9 @@ def main():
                          "to measure what that step costs per frame")
     ap.add_argument("--stub-renderer", action="store_true",
                     help="TEST HOOK: run the multi-rank control flow on CPU (gloo) with a renderer that renders nothing")
+    ap.add_argument("--display-lag", type=int, default=0, metavar="FRAMES",
+                    help="--progressive: 0 = one host sync per frame; n = every frame's image is copied out on the stream and the host waits "
+                         "for the copy of the frame n behind (a display loop that runs n frames behind the renderer)")
     ap.add_argument("--progressive", type=int, default=0, metavar="SPF",
                     help="instead of the offline frame: time render_progressive-style frames of SPF samples each "
                          "(pt_render_accumulate; the reference UI's default is 2, main.cu:131) and report frames/s")

@@ -13,8 +13,9 @@ for S in cbox bunny buddha_standin dragon_standin; do
   python3 bench.py --scene $S --tree caller --no-cpu-baseline > gpurun_out/${TAG}_bench_${S}_callers_tree.json 2>/dev/null
   python3 -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_${S}_callers_tree.json')); print('$S caller tree', d['ms_per_step'], d['value'])"
 done
-for S in scene1 cbox bunny; do python3 bench.py --scene $S --progressive 2 --steps 200 --warmup 20; done > gpurun_out/${TAG}_bench_progressive.jsonl 2>/dev/null
+# interactive shape: 2 samples per frame; a host sync per frame, then a display that runs one frame behind the renderer
+for LAG in 0 1; do for S in scene1 cbox bunny; do python3 bench.py --scene $S --progressive 2 --steps 400 --warmup 20 --display-lag $LAG; done; done > gpurun_out/${TAG}_bench_progressive.jsonl 2>/dev/null
 cat gpurun_out/${TAG}_bench_progressive.jsonl | python3 -c "
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print(d['metric'][:60], d['value'])"
+    d=json.loads(l); print(d['metric'][:60], 'display lag', d['config'].get('display_lag'), d['value'])"

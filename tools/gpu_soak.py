@@ -1,7 +1,10 @@
 """Soak test: many back-to-back frames over scenes / traversal modes / kernel variants / shard shapes; every frame must
-be bit-identical to the first one of its configuration.  Catches rare scheduling-dependent bugs and hangs."""
+be bit-identical to the first one of its configuration.  Catches rare scheduling-dependent bugs and hangs.
+Every third iteration submits a BURST of 2-5 frames without a host sync in between (pt_render_async on one or two caller
+streams, frames_in_flight 1-4): overlapping launches, slot reuse, partial grids — each frame of the burst must be that same image."""
 import os, sys, time
 import numpy as np
+import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from pathtracer_cuda_interactive_amd import HostScene, PT_BVH_SORT_REFERENCE, PT_RENDER_NEE, PT_TRAVERSAL_EXACT, PT_TRAVERSAL_PRUNED
@@ -13,6 +16,8 @@ for name in ("cbox", "scene1", "scene1_phong", "teapot", "bunny"):
     hs = HostScene.load(os.path.join(REPO, "tests", "golden", "scenes", name + ".pts"))
     scenes[name] = (hs, dev.DeviceScene(hs.finalize(PT_BVH_SORT_REFERENCE)))
 ref = {}
+caller_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+frames = 0
 t0 = time.time()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 for it in range(n):
@@ -37,13 +42,33 @@ for it in range(n):
     p = hs.render_params(w, h, spp)
     p.flags = PT_RENDER_NEE if nee else 0
     p.row_begin, p.row_end, p.row_stride = it % stride, h, stride
-    img = ds.render(p, traversal=trav)
+    ds.set_option("frames_in_flight", [2, 1, 3, 4][(it // 3) % 4])
     key = (name, w, h, spp, p.row_begin, stride, nee)
+    if it % 3 == 2:
+        burst = [2, 3, 5, 4][(it // 9) % 4]
+        rows = len(range(p.row_begin, h, stride))
+        streams = caller_streams[: 1 + (it // 27) % 2]
+        outs = [torch.empty(rows, w, 3, dtype=torch.float32, device="cuda") for _ in range(burst)]
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            ds.render_into(p, o.data_ptr(), stream=streams[k % len(streams)].cuda_stream, traversal=trav)
+        torch.cuda.synchronize()
+        frames += burst
+        imgs = [o.cpu().numpy() for o in outs]
+        if key not in ref:
+            ref[key] = imgs[0]
+        if not all((ref[key].view(np.uint32) == im.reshape(ref[key].shape).view(np.uint32)).all() for im in imgs):
+            print("MISMATCH in a burst at iteration", it, key, "kernel", kernel, "burst", burst)
+            sys.exit(1)
+        img = ref[key]
+    else:
+        img = ds.render(p, traversal=trav)
+        frames += 1
     if key not in ref:
         ref[key] = img
     elif not (ref[key].view(np.uint32) == img.view(np.uint32)).all():
         print("MISMATCH at iteration", it, key, "kernel", kernel)
         sys.exit(1)
     if it % 100 == 99:
-        print(f"{it + 1} frames ok, {time.time() - t0:.1f} s", flush=True)
-print("soak ok:", n, "frames,", len(ref), "distinct configurations")
+        print(f"{it + 1} iterations ({frames} frames) ok, {time.time() - t0:.1f} s", flush=True)
+print("soak ok:", n, "iterations,", frames, "frames,", len(ref), "distinct configurations")
