@@ -94,6 +94,8 @@ def progressive_mode(args, hs, desc, wl):
     spf = args.progressive
     W, H = 640, 480
     ds = DeviceScene(desc)
+    if not args.frame_timing:
+        ds.set_option("timing_frames", 0)        # an interactive loop has no use for per-frame kernel times: no HIP events around the kernels
     for kv in args.set:
         k, v = kv.split("=")
         ds.set_option(k, int(v))
@@ -137,7 +139,7 @@ def progressive_mode(args, hs, desc, wl):
            "data": "synthetic: scene fixture, PCG seed 1984",
            "config": {"workload": f"{wl['label'].split(' (')[0].rsplit(' ', 2)[0]} 640x480, {spf} spp per frame, accumulate + "
                                   + ("host sync per frame" if lag == 0 else f"copy-out per frame, the host waits for the frame {lag} behind"),
-                      "display_lag": lag, "frames_in_flight": int(ds.info("frames_in_flight")),
+                      "display_lag": lag, "frames_in_flight": int(ds.info("frames_in_flight")), "frame_timing_events": bool(args.frame_timing),
                       "kernel_ms_last_frame": round(c.kernel_ms, 4), "segments_last_frame": int(c.segments),
                       "reference_fps_rtx3080_with_ui": list(ref) if ref else None,
                       "note": "reference FPS includes its CPU tonemap + OpenGL upload per frame; this number has no display"}}
@@ -292,6 +294,8 @@ def main():
                          "to measure what that step costs per frame")
     ap.add_argument("--stub-renderer", action="store_true",
                     help="TEST HOOK: run the multi-rank control flow on CPU (gloo) with a renderer that renders nothing")
+    ap.add_argument("--frame-timing", action="store_true",
+                    help="--progressive: keep the library's per-frame HIP timing events (four event records per frame; default off there)")
     ap.add_argument("--display-lag", type=int, default=0, metavar="FRAMES",
                     help="--progressive: 0 = one host sync per frame; n = every frame's image is copied out on the stream and the host waits "
                          "for the copy of the frame n behind (a display loop that runs n frames behind the renderer)")

@@ -1019,6 +1019,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
     { int grc = guard.enter(S->device); if (grc) return grc; }
     // this call's frame slot (see pt_scene::FrameSlot)
     const int in_flight = (int)std::min<int64_t>(kMaxFramesInFlight, std::max<int64_t>(1, S->opt_frames_in_flight));
+    const bool timing = S->opt_timing_frames > 0;        // 0: no HIP events around the kernels (four records less per frame)
     // Is the previous call's frame still on the GPU?  If not there is nothing to overlap with, and this frame runs on the
     // caller's stream as with one slot: a caller that synchronises after every frame (a display loop) does not pay for two
     // event waits across streams per frame.
@@ -1212,7 +1213,7 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
                  : per_wave >= 4 * kMaxChunk ? kMaxChunk : (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(kMaxChunk, (per_wave / 64) * 64));
         if (S->opt_chunk > 0) rd.chunk = (uint32_t)std::min<int64_t>(kMaxChunk, std::max<int64_t>(64, (S->opt_chunk / 64) * 64));
 
-        if (frec.ev.size() <= (size_t)pass) {
+        if (timing && frec.ev.size() <= (size_t)pass) {
             pt_scene::PassEvents fresh{};
             hipError_t ee = hipEventCreate(&fresh.t0);
             if (ee == hipSuccess && (ee = hipEventCreate(&fresh.t1)) != hipSuccess) (void)hipEventDestroy(fresh.t0);
@@ -1221,9 +1222,9 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
             if (ee != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(ee));
             frec.ev.push_back(fresh);
         }
-        const pt_scene::PassEvents pe = frec.ev[pass];
+        const pt_scene::PassEvents pe = timing ? frec.ev[pass] : pt_scene::PassEvents{};
         if (pass > 0) HIP_TRY(hipMemsetAsync(slot.ctl.p, 0, kWorkBytes, tstream));
-        HIP_TRY(hipEventRecord(pe.t0, tstream));
+        if (timing) HIP_TRY(hipEventRecord(pe.t0, tstream));
         if (use_q)
             hipLaunchKernelGGL(fnq, dim3(grid), dim3(kQBlock), lp.total, tstream, S->dev, rd, lp, qp, slot.samples.p,
                                S->work_counter(), S->counters());
@@ -1231,9 +1232,9 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
             hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), lp.total, tstream, S->dev, rd, lp, slot.samples.p,
                                S->work_counter(), S->counters());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(pe.t1, tstream));
+        if (timing) HIP_TRY(hipEventRecord(pe.t1, tstream));
         if (own_stream) HIP_TRY(hipStreamWaitEvent(tstream, slot.in_ev, 0));   // the resolve writes the caller's buffer
-        HIP_TRY(hipEventRecord(pe.r0, tstream));
+        if (timing) HIP_TRY(hipEventRecord(pe.r0, tstream));
 
         const bool first = pass == 0, last = pass == n_pass - 1;
         int rmode;
@@ -1251,14 +1252,14 @@ int launch_render(pt_scene* S, const pt_render_params* p, float* out_dev, int mo
         hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, tstream, slot.samples.p, accum,
                            out_dev, (uint32_t)npix, sn, rmode, rfirst, scale);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(pe.r1, tstream));
+        if (timing) HIP_TRY(hipEventRecord(pe.r1, tstream));
         HIP_TRY(hipEventRecord(slot.free_ev, tstream));
         slot.used = true; slot.free_stream = tstream;
         if (own_stream) HIP_TRY(hipStreamWaitEvent(stream, slot.free_ev, 0));
         S->info_passes++;
-        frec.passes = (size_t)pass + 1;
+        if (timing) frec.passes = (size_t)pass + 1;
     }
-    S->have_timing = true;
+    S->have_timing = timing;
     return PT_OK;
 }
 
@@ -1413,7 +1414,7 @@ int pt_scene_set_option(pt_scene* S, const char* key, int64_t value) {
     else if (k == "item_order") S->opt_item_order = value;
     else if (k == "specialize") S->opt_specialize = value;
     else if (k == "timing_frames") {
-        if (value < 1 || value > 4096) return fail(PT_ERR_INVALID_ARG, "timing_frames must be 1 .. 4096");
+        if (value < 0 || value > 4096) return fail(PT_ERR_INVALID_ARG, "timing_frames must be 0 .. 4096");
         S->opt_timing_frames = value;
     }
     else if (k == "kernel") { if (value < 1 || value > 3) return fail(PT_ERR_INVALID_ARG, "kernel must be 1, 2 or 3"); S->opt_kernel = value; }

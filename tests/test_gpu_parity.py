@@ -531,6 +531,17 @@ def test_frame_times_of_frames_enqueued_without_a_host_sync(oracle):
         assert c.kernel_ms == k[-1]
         assert_bit_equal(out.cpu().numpy(), want, "last of seven frames enqueued back to back")
         with pytest.raises(PtError):
-            ds.set_option("timing_frames", 0)
+            ds.set_option("timing_frames", -1)
+        # 0 = no timing events: same frame, same work counters, times read zero
+        ds.set_option("timing_frames", 0)
+        out.zero_()
+        for _ in range(3):
+            ds.render_into(p, out.data_ptr(), stream)
+        c0 = ds.counters()
+        assert (c0.paths, c0.segments) == (c.paths, c.segments) and c0.kernel_ms == 0 and c0.resolve_ms == 0
+        assert_bit_equal(out.cpu().numpy(), want, "frames rendered without timing events")
+        ds.set_option("timing_frames", 2)
+        ds.render_into(p, out.data_ptr(), stream)
+        assert ds.counters().kernel_ms > 0
     finally:
         ds.close()
