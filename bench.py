@@ -503,6 +503,9 @@ def main():
                        "tree": ("stub" if stub else "internal" if R.scene.info("fast_tree_on") else "caller"),
                        "stack_entries": 0 if stub else int(R.scene.info("stack_entries")),
                        "host_sync_per_step": False, "forced_gather": force_gather, "frames_in_flight": in_flight,
+                       "kernel_ms_note": ("launches of consecutive frames overlap on the chip (frames_in_flight): kernel_ms is the HIP-event "
+                                          "duration of one launch, about roofline.launch_overlap frame intervals; ms_per_step is the frame interval")
+                                         if overlapped else None,
                        "work": work,
                        "frame_mean": round(float(frame.mean().item()), 6)},
             "roofline": roofline,
