@@ -84,11 +84,15 @@ struct Cand {                   // a cut of a node: total order (cost, off, axis
     int32_t ak;                 // axis << 28 | k
 };
 struct CandMin {
+    // field-wise selects on one predicate: returning one of the two operands whole makes the compiler select between their
+    // ADDRESSES, which puts arrays of candidates into scratch memory (tile_cand_kernel: 224 B per lane)
     __host__ __device__ Cand operator()(const Cand& a, const Cand& b) const {
-        if (b.cost < a.cost) return b;
-        if (a.cost < b.cost) return a;
-        if (b.off != a.off) return b.off < a.off ? b : a;
-        return b.ak < a.ak ? b : a;
+        const bool take_b = b.cost < a.cost ? true : a.cost < b.cost ? false : b.off != a.off ? b.off < a.off : b.ak < a.ak;
+        Cand r;
+        r.cost = take_b ? b.cost : a.cost;
+        r.off = take_b ? b.off : a.off;
+        r.ak = take_b ? b.ak : a.ak;
+        return r;
     }
 };
 __device__ __forceinline__ Cand cand_none() { return Cand{__builtin_huge_val(), 0x7fffffff, 0x7fffffff}; }
@@ -154,13 +158,17 @@ struct FSB {
     SB v;
     uint32_t head;              // 1: a segment starts here (in scan direction); 2: nothing (identity)
 };
-struct SegMerge {
+struct SegMerge {             // (field-wise selects, no whole-operand returns: see CandMin)
     __device__ FSB operator()(const FSB& a, const FSB& b) const {
-        if (b.head == 2u) return a;
-        if (b.head == 1u || a.head == 2u) return b;
+        const bool keep_a = b.head == 2u;
+        const bool take_b = !keep_a && (b.head == 1u || a.head == 2u);
+        const SB m = MergeKeepFirst()(a.v, b.v);
         FSB r;
-        r.v = MergeKeepFirst()(a.v, b.v);
-        r.head = a.head;
+        for (int k = 0; k < 3; k++) {
+            r.v.lo[k] = keep_a ? a.v.lo[k] : take_b ? b.v.lo[k] : m.lo[k];
+            r.v.hi[k] = keep_a ? a.v.hi[k] : take_b ? b.v.hi[k] : m.hi[k];
+        }
+        r.head = take_b ? b.head : a.head;
         return r;
     }
 };
@@ -180,11 +188,14 @@ struct FC {
 };
 struct SegMin {
     __device__ FC operator()(const FC& a, const FC& b) const {
-        if (b.head == 2u) return a;
-        if (b.head == 1u || a.head == 2u) return b;
+        const bool keep_a = b.head == 2u;
+        const bool take_b = !keep_a && (b.head == 1u || a.head == 2u);
+        const Cand m = CandMin()(a.c, b.c);
         FC r;
-        r.c = CandMin()(a.c, b.c);
-        r.head = a.head;
+        r.c.cost = keep_a ? a.c.cost : take_b ? b.c.cost : m.cost;
+        r.c.off = keep_a ? a.c.off : take_b ? b.c.off : m.off;
+        r.c.ak = keep_a ? a.c.ak : take_b ? b.c.ak : m.ak;
+        r.head = take_b ? b.head : a.head;
         return r;
     }
 };
@@ -275,6 +286,17 @@ __global__ __launch_bounds__(kCarryT) void cand_carry_kernel(const FC* __restric
         run = SegMin()(run, in[p]);
     }
 }
+// inclusive SegMerge scan of a tile, kScanI consecutive items per thread: the thread's own items in registers, one block scan over
+// the threads' totals (hipcub's array form keeps its items in scratch memory here: 224 B per lane)
+template <class ScanT>
+__device__ __forceinline__ void tile_scan(FSB (&it)[kScanI], typename ScanT::TempStorage& tmp) {
+#pragma unroll
+    for (int j = 1; j < kScanI; j++) it[j] = SegMerge()(it[j - 1], it[j]);
+    FSB before;
+    ScanT(tmp).ExclusiveScan(it[kScanI - 1], before, fsb_none(), SegMerge());
+#pragma unroll
+    for (int j = 0; j < kScanI; j++) it[j] = SegMerge()(before, it[j]);
+}
 // (C) best cut after every position (cand3_kernel's arithmetic, operand for operand) and the node's box at its first position
 __global__ __launch_bounds__(kScanT) void tile_cand_kernel(const SB3 bx, const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_e,
                                                            int n, int tiles, const FSB* __restrict__ carry, Cand* __restrict__ best_at_end,
@@ -286,6 +308,7 @@ __global__ __launch_bounds__(kScanT) void tile_cand_kernel(const SB3 bx, const u
     const int tile = blockIdx.x, base = tile * kTile, t = threadIdx.x;
     uint32_t sb[kScanI], se[kScanI];
     Cand c[kScanI];
+#pragma unroll
     for (int j = 0; j < kScanI; j++) {
         const int i = tile_pos(base, t, j, false);
         sb[j] = i < n ? seg_b[i] : 0u;
@@ -295,9 +318,11 @@ __global__ __launch_bounds__(kScanT) void tile_cand_kernel(const SB3 bx, const u
     FSB it[kScanI];
     for (int a = 0; a < 3; a++) {
         // suffix boxes: right to left, into LDS by position; suf_sh[kTile] = the run that starts right of the tile
+#pragma unroll
         for (int j = 0; j < kScanI; j++) it[j] = tile_item(bx.a[a], seg_b, seg_e, n, tile_pos(base, t, j, true), true);
-        Scan(tmp).InclusiveScan(it, it, SegMerge());
+        tile_scan<Scan>(it, tmp);
         const FSB cr = carry[(size_t)(a * 2 + 1) * tiles + tile];
+#pragma unroll
         for (int j = 0; j < kScanI; j++) {
             const int i = tile_pos(base, t, j, true);
             if (i < n) suf_sh[i - base] = it[j].head ? it[j].v : MergeKeepFirst()(cr.v, it[j].v);   // no segment end in [i, tile end): it runs on
@@ -305,9 +330,11 @@ __global__ __launch_bounds__(kScanT) void tile_cand_kernel(const SB3 bx, const u
         if (t == 0) suf_sh[kTile] = cr.v;
         __syncthreads();
         // prefix boxes: left to right, in registers
+#pragma unroll
         for (int j = 0; j < kScanI; j++) it[j] = tile_item(bx.a[a], seg_b, seg_e, n, tile_pos(base, t, j, false), false);
-        Scan(tmp).InclusiveScan(it, it, SegMerge());
+        tile_scan<Scan>(it, tmp);
         const FSB cf = carry[(size_t)(a * 2 + 0) * tiles + tile];
+#pragma unroll
         for (int j = 0; j < kScanI; j++) {
             const int i = tile_pos(base, t, j, false);
             if (i >= n) continue;
@@ -328,14 +355,17 @@ __global__ __launch_bounds__(kScanT) void tile_cand_kernel(const SB3 bx, const u
     }
     // the running minimum of every node up to each position; kept where a node ends, and the tile's aggregate for the carries
     FC fc[kScanI];
+#pragma unroll
     for (int j = 0; j < kScanI; j++) {
         const int i = tile_pos(base, t, j, false);
         fc[j] = i < n ? FC{c[j], (uint32_t)i == sb[j] ? 1u : 0u} : fc_none();
     }
     FC local = fc_none();
+#pragma unroll
     for (int j = 0; j < kScanI; j++) local = SegMin()(local, fc[j]);
     FC total;
     FC run = block_exclusive_min<kScanT>(local, reinterpret_cast<FC*>(suf_sh), total);     // (the axis loop ended with a barrier)
+#pragma unroll
     for (int j = 0; j < kScanI; j++) {
         const int i = tile_pos(base, t, j, false);
         run = SegMin()(run, fc[j]);
