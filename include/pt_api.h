@@ -286,6 +286,10 @@ int pt_bvh_build_sweep_device(const pt_scene_desc* desc, pt_bvh_node* out_nodes,
  * internal tree built, ... re-laid, uploads + probe, tie tables). */
 int pt_scene_set_option(pt_scene* scene, const char* key, int64_t value);
 int pt_scene_get_info(pt_scene* scene, const char* key, int64_t* value);
+/* Environment variables the library reads (A/B runs and debugging; results are the same whatever they say):
+ *   PT_SWEEP_BUILD=host              pt_scene_create prepares big scenes on the host as in round 2 (default: on the device from 4,096 shapes)
+ *   PT_SWEEP_SCANS=rocprim           the device sweep builder's box scans as rocPRIM scans-by-key (default: tiled)
+ *   PT_SLOT_STREAM_PRIORITY=normal|high   priority of the handle's own streams (default: lowest) */
 
 /* Deterministic fp32 helpers evaluated ON THE DEVICE, exported so tests can
  * pin device arithmetic against the CPU oracle bit-for-bit.
