@@ -86,9 +86,23 @@ def build_example(force=False):
     return EXAMPLE_BIN
 
 
+INTERACTIVE_BIN = os.path.join(REPO_DIR, "examples", "interactive_main")
+
+
+def build_interactive_example(force=False):
+    """The reference's interactive accumulation loop on the C ABI + the HIP runtime (examples/interactive_main.cpp)."""
+    src = os.path.join(REPO_DIR, "examples", "interactive_main.cpp")
+    if force or _newer(INTERACTIVE_BIN, [src, HOST_LIB, HIP_LIB] + _glob(INCLUDE, (".h",))):
+        _run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-std=c++17", "-O2", "-Wall", "-I", INCLUDE, src, "-L", PKG_DIR, "-lpt_host", "-lpt_hip",
+              "-Wl,-rpath," + PKG_DIR, "-Wl,-rpath,$ORIGIN/../pathtracer_cuda_interactive_amd", "-Wl,-rpath,/opt/rocm/lib",
+              "-o", INTERACTIVE_BIN])
+    return INTERACTIVE_BIN
+
+
 def build_all(force=False):
     out = build_host(force), build_hip(force)
     build_example(force)
+    build_interactive_example(force)
     return out
 
 

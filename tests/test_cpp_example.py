@@ -51,3 +51,27 @@ def test_example_with_device_tree_and_nee(oracle, binary, tmp_path):
     p.flags = PT_RENDER_NEE
     want, _ = oracle.render(d2, p)
     assert_bit_equal(read_pfm(out), want, "teapot, device SAH tree, NEE")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lag", [0, 1, 2])
+def test_interactive_example_accumulates_the_oracle_image(oracle, tmp_path, lag):
+    """examples/interactive_main.cpp: the reference's interactive loop (render_progressive + display, main.cu:272-344) on the C ABI
+    and the HIP runtime.  With the display one or two frames behind, consecutive frames overlap on the GPU; the accumulated image
+    is the sum the oracle makes frame by frame, bit for bit, whatever the lag."""
+    binary = _build.build_interactive_example()
+    out = tmp_path / "accum.pfm"
+    W, H, spf, frames = 48, 36, 2, 9
+    r = subprocess.run([binary, f"{SCENES}/cbox.pts", str(out), str(W), str(H), str(spf), str(frames), str(lag)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "frames/s" in r.stdout
+    hs, d = load_scene("cbox")
+    want = None
+    for f in range(frames):
+        p = hs.render_params(W, H, spf)
+        p.sample_offset, p.stream_stride = f * spf, spf * frames
+        part, _ = oracle.render(d, p, accumulate=True)
+        want = part if f == 0 else (want + part).astype(np.float32)
+    want = (want * np.float32(1.0 / np.float32(spf * frames))).astype(np.float32)
+    assert_bit_equal(read_pfm(out), want, f"interactive loop, display {lag} frame(s) behind")
