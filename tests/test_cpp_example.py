@@ -75,3 +75,11 @@ def test_interactive_example_accumulates_the_oracle_image(oracle, tmp_path, lag)
         want = part if f == 0 else (want + part).astype(np.float32)
     want = (want * np.float32(1.0 / np.float32(spf * frames))).astype(np.float32)
     assert_bit_equal(read_pfm(out), want, f"interactive loop, display {lag} frame(s) behind")
+
+
+@pytest.mark.skipif(_gpu_available(), reason="only meaningful on a box without a GPU")
+def test_interactive_example_fails_loudly_without_a_gpu(tmp_path):
+    binary = _build.build_interactive_example()
+    r = subprocess.run([binary, f"{SCENES}/cbox.pts", str(tmp_path / "x.pfm"), "16", "12", "1", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    assert subprocess.run([binary], capture_output=True).returncode == 2            # usage
