@@ -153,7 +153,10 @@ __global__ void cand3_kernel(const SB3 pre, const SB3 suf, const uint32_t* __res
 // segmented scan over the aggregates, six small blocks), (C) per tile and order both scans again with their carries, the suffix
 // boxes through LDS, the prefix boxes in registers, and the best cut after every position straight out: 168 B per element.
 // The operator is the segmented form of MergeKeepFirst — (earlier, later) in scan order, so the bits are the sequential sweep's.
-constexpr int kScanT = 256, kScanI = 4, kTile = kScanT * kScanI;
+#ifndef PT_SWEEP_ITEMS
+#define PT_SWEEP_ITEMS 4
+#endif
+constexpr int kScanT = 256, kScanI = PT_SWEEP_ITEMS, kTile = kScanT * kScanI;
 struct FSB {
     SB v;
     uint32_t head;              // 1: a segment starts here (in scan direction); 2: nothing (identity)
