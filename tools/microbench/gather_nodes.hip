@@ -3,6 +3,8 @@
 //   B: quad-cooperative: the 4 lanes of a quad load the 4 x 16 B pieces of ONE node per instruction (coalesced 64 B),
 //      4 instructions cover the quad's 4 nodes; data is then exchanged inside the quad with DPP
 //   C: like A but each lane loads only 16 B (lower bound for "one request per lane")
+//   E: 32-byte nodes (a second table with a 32-B stride): 2 x global_load_dwordx4 per lane — what a node with conservatively
+//      quantised child boxes would cost ("next candidate")
 //   D: quad-cooperative through LDS: the same coalesced 64-B reads as B, but issued as LDS-DMA (global_load_lds_dwordx4:
 //      lane l's 16 B land at tile + l*16), so that after 4 instructions quad q's member-m node sits at tile_m + q*64 and
 //      every lane reads its own node back with ds_read_b128 — no DPP exchange, no selects
@@ -34,6 +36,9 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ nodes, 
         } else if (MODE == 2) {
             const float4* p = nodes + (size_t)idx * 4;
             a = p[0]; b = a; c = a; d = a;
+        } else if (MODE == 4) {
+            const float4* p = nodes + (size_t)idx * 2;          // `nodes` is the 32-B table here; its second piece carries the index in .x
+            a = p[0]; d = p[1]; b = a; c = a;
         } else if (MODE == 3) {
             const uint32_t i0 = __builtin_amdgcn_mov_dpp(idx, 0x00, 0xf, 0xf, true);
             const uint32_t i1 = __builtin_amdgcn_mov_dpp(idx, 0x55, 0xf, 0xf, true);
@@ -94,6 +99,12 @@ int main(int argc, char** argv) {
     std::vector<float> h((size_t)n_nodes * 16);
     for (uint32_t i = 0; i < n_nodes; i++)
         for (int k = 0; k < 16; k++) h[(size_t)i * 16 + k] = (k == 12) ? __builtin_bit_cast(float, i * 2654435761u) : float(i % 97) + k;
+    std::vector<float> h32((size_t)n_nodes * 8);
+    for (uint32_t i = 0; i < n_nodes; i++)
+        for (int k = 0; k < 8; k++) h32[(size_t)i * 8 + k] = (k == 4) ? __builtin_bit_cast(float, i * 2654435761u) : float(i % 97) + k;
+    float4* d32;
+    CHECK(hipMalloc(&d32, h32.size() * 4));
+    CHECK(hipMemcpy(d32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
     float4* d; uint32_t* out;
     const int blocks = 256 * 6;
     CHECK(hipMalloc(&d, h.size() * 4)); CHECK(hipMalloc(&out, blocks * 256 * 4));
@@ -101,21 +112,22 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<uint32_t> r0(blocks * 256), r1(blocks * 256);
     printf("hot steps: %u of 8\n", hot);
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         float best = 1e9;
         for (int rep = 0; rep < 5; rep++) {
             CHECK(hipEventRecord(e0));
             if (mode == 0) gather<0><<<blocks, 256>>>(d, n_nodes, steps, out, hot);
             else if (mode == 1) gather<1><<<blocks, 256>>>(d, n_nodes, steps, out, hot);
             else if (mode == 2) gather<2><<<blocks, 256>>>(d, n_nodes, steps, out, hot);
-            else gather<3><<<blocks, 256>>>(d, n_nodes, steps, out, hot);
+            else if (mode == 3) gather<3><<<blocks, 256>>>(d, n_nodes, steps, out, hot);
+            else gather<4><<<blocks, 256>>>(d32, n_nodes, steps, out, hot);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
         }
         CHECK(hipMemcpy(mode == 0 ? r0.data() : r1.data(), out, blocks * 256 * 4, hipMemcpyDeviceToHost));
         const double fetches = double(blocks) * 256 * steps;
         printf("mode %d (%s): %.3f ms, %.2f G node fetches/s, %.1f cycles per wave-step per CU @2.4GHz\n", mode,
-               mode == 0 ? "own node, 4 x dwordx4" : mode == 1 ? "quad-cooperative + DPP transpose" : mode == 2 ? "own node, 1 x dwordx4 only" : "quad-cooperative LDS-DMA + ds_read",
+               mode == 0 ? "own node, 4 x dwordx4" : mode == 1 ? "quad-cooperative + DPP transpose" : mode == 2 ? "own node, 1 x dwordx4 only" : mode == 3 ? "quad-cooperative LDS-DMA + ds_read" : "32-B nodes, 2 x dwordx4",
                best, fetches / best / 1e6, best * 1e-3 * 2.4e9 / (fetches / 64 / 256));
         if (mode == 1 || mode == 3) { size_t bad = 0; for (size_t i = 0; i < r0.size(); i++) bad += r0[i] != r1[i]; printf("  mode %d vs mode 0 mismatches: %zu\n", mode, bad); }
     }
