@@ -685,10 +685,13 @@ int validate_and_build(const pt_scene_desc* d, pt_scene* S) {
         DevBuf<unsigned long long> visits;
         if ((rc = visits.ensure(2))) return rc;
         HIP_TRY(hipMemset(visits.p, 0, 2 * sizeof(unsigned long long)));
-        for (int t = 0; t < 2; t++) {
-            select_tree(S, t);
-            const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)S->dev.stack_cap * 64u * 4u;
-            hipLaunchKernelGGL(probe_kernel, dim3(kProbeRays / kBlock), dim3(kBlock), lds, nullptr, S->dev, visits.p + t);
+        {
+            select_tree(S, 0);
+            const SceneDev d0 = S->dev;
+            select_tree(S, 1);
+            const SceneDev d1 = S->dev;
+            const uint32_t lds = (uint32_t)(kBlock / 64) * (uint32_t)std::max(d0.stack_cap, d1.stack_cap) * 64u * 4u;
+            hipLaunchKernelGGL(probe_kernel, dim3(kProbeRays / kBlock, 2), dim3(kBlock), lds, nullptr, d0, d1, visits.p);
             HIP_TRY(hipGetLastError());
         }
         unsigned long long v[2] = {0, 0};

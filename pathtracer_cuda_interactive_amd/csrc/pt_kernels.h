@@ -650,8 +650,12 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneDev scn, const f
 // Inner-node visits of a fixed set of probe rays through the tree `scn` points at (pt_api.hip: validate_and_build chooses
 // between the caller's tree and the internal one by this count).  Ray k starts on primitive hash(k) mod N — its centroid,
 // or the point of a sphere facing the direction — and leaves into a uniform direction: the shape of a segment after a bounce.
-__global__ __launch_bounds__(kBlock) void probe_kernel(SceneDev scn, unsigned long long* __restrict__ visits) {
+// Both trees in one launch: blockIdx.y picks the tree and its counter (two launches of 128 blocks each ran one after the other
+// on half a chip).
+__global__ __launch_bounds__(kBlock) void probe_kernel(SceneDev scn0, SceneDev scn1, unsigned long long* __restrict__ visits2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SceneDev& scn = blockIdx.y ? scn1 : scn0;
+    unsigned long long* visits = visits2 + blockIdx.y;
     ptd::SceneView sv;
     sv.nodes = scn.nodes; sv.prims = scn.prims; sv.normals = scn.normals;
     sv.materials = scn.materials; sv.emission = scn.emission; sv.lights = scn.lights;
